@@ -1,0 +1,150 @@
+/*
+ * plonk_mi355x.h -- C ABI of the MI355X (gfx950) backend for the PLONK prover hot path:
+ * BLS12-381 Fr radix-2 NTT / iNTT / coset-NTT and G1 variable-base MSM (KZG commit).
+ *
+ * Drop-in boundary.  The reference (Manta-Network/Plonk-Prototype) reaches this path only
+ * through its dependencies (ref:Cargo.toml:19 `dusk-plonk = 0.8.2`, ref:Cargo.toml:20
+ * `dusk-bls12_381 = 0.8`): there is no FFI or plugin interface upstream, `best_fft` and
+ * `msm_variable_base` are plain Rust functions.  The entry points below are therefore
+ * exactly what a `-sys` crate for a `[patch.crates-io]` fork of those two crates binds
+ * (INTEGRATION.md shows the Rust side):
+ *
+ *   pm_fr_ntt / pm_fr_ntt_batch  <- dusk_plonk::fft::EvaluationDomain::{fft, ifft, coset_fft,
+ *                                   coset_ifft}(_in_place)   [ark-poly: EvaluationDomain::
+ *                                   {fft, ifft, coset_fft, coset_ifft}]   SURVEY.md 8a a3-a7
+ *   pm_domain_info               <- EvaluationDomain::new  (group_gen, group_gen_inv,
+ *                                   size_inv; error when log2(size) >= 32)  SURVEY.md 8a a2
+ *   pm_g1_bases_upload           <- CommitKey { powers_of_g }  (device-resident SRS)   a10
+ *   pm_g1_msm                    <- dusk_bls12_381::multiscalar_mul::msm_variable_base
+ *                                   [ark-ec: VariableBaseMSM::multi_scalar_mul]        a9
+ *   pm_g1_fold / pm_g1_to_affine <- G1Projective `+` / G1Affine::from (multi-GPU fold)  a8
+ *
+ * Data layouts are the Rust types' memory, so slices can be passed without marshalling:
+ *   Fr  (BlsScalar / ark Fr)  : 4 x uint64_t little-endian limbs, Montgomery form R = 2^256,
+ *                               fully reduced.  32 bytes, 8-byte aligned.
+ *   Fp                        : 6 x uint64_t little-endian limbs, Montgomery form R = 2^384.
+ *   G1 affine base            : x[6] | y[6]  (96 bytes packed).  The point at infinity is
+ *                               encoded as x = y = 0 (not on the curve, so unambiguous).
+ *   G1 projective result      : X[6] | Y[6] | Z[6] (144 bytes), always normalised to Z = 1
+ *                               (Montgomery one) or (0, 1, 0) for the identity -- valid both
+ *                               as dusk/zkcrypto homogeneous and as ark Jacobian coordinates.
+ *
+ * Ownership: the caller owns every host buffer; the library never keeps a host pointer past
+ * return.  pm_ctx / pm_bases are library-owned handles freed by pm_shutdown / pm_g1_bases_free.
+ * Errors: every call returns PM_OK (0) or a negative pm_status; nothing unwinds across the
+ * ABI.  pm_last_error(ctx) gives a human-readable string for the last failure on that ctx.
+ * Threading: calls on one ctx are serialised by an internal mutex; use one ctx per thread
+ * for concurrency.  One ctx drives one GPU (one process per GPU under torch.distributed).
+ * There is no CPU fallback: without a usable gfx950 device pm_init fails with
+ * PM_ERR_NO_DEVICE.
+ */
+#ifndef PLONK_MI355X_H
+#define PLONK_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pm_ctx pm_ctx;
+typedef struct pm_bases pm_bases;
+
+typedef enum {
+  PM_OK = 0,
+  PM_ERR_BAD_ARG = -1,
+  PM_ERR_DOMAIN_TOO_LARGE = -2, /* log_n >= 32 = Fr two-adicity (EvaluationDomain::new fails) */
+  PM_ERR_OOM = -3,
+  PM_ERR_HIP = -4,
+  PM_ERR_NO_DEVICE = -5,
+  PM_ERR_LENGTH = -6            /* in_len > 2^log_n, or n > number of uploaded bases */
+} pm_status;
+
+/* pm_fr_ntt flags */
+#define PM_NTT_FORWARD 0u
+#define PM_NTT_INVERSE 1u /* use group_gen_inv and scale by size_inv (ifft) */
+#define PM_NTT_COSET 2u   /* fft: pre-scale a[i] *= 7^i ; with INVERSE: post-scale a[i] *= 7^-i */
+
+/* pm_g1_msm scalar_form */
+#define PM_SCALAR_MONTGOMERY 0u /* dusk `&[BlsScalar]` memory */
+#define PM_SCALAR_CANONICAL 1u  /* ark `&[BigInteger256]` memory (plain integers < r) */
+
+const char* pm_version(void);
+
+/* Create a context on HIP device `device_id` (stream, twiddle caches, workspaces). */
+int pm_init(int device_id, pm_ctx** out);
+void pm_shutdown(pm_ctx* ctx);
+const char* pm_last_error(const pm_ctx* ctx);
+/* Block until everything queued on the context's stream has finished. */
+int pm_sync(pm_ctx* ctx);
+
+/* ---- EvaluationDomain ------------------------------------------------------------------ */
+
+/* EvaluationDomain::new(2^log_n): writes group_gen, group_gen_inv, size_inv (Montgomery Fr).
+ * Pure host arithmetic, needs no context.  PM_ERR_DOMAIN_TOO_LARGE when log_n >= 32. */
+int pm_domain_info(uint32_t log_n, uint64_t group_gen[4], uint64_t group_gen_inv[4],
+                   uint64_t size_inv[4]);
+
+/* Build (and cache on the device) the twiddle tables of the 2^log_n domain.  Optional: the
+ * first transform of a size does it implicitly. */
+int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n);
+
+/* out[0 .. 2^log_n) = transform of in[0 .. in_len) zero-padded to 2^log_n (the reference's
+ * `resize(size, zero)`).  Natural order in and out, canonical Montgomery limbs.
+ * in == out is allowed (the *_in_place forms).  Host pointers. */
+int pm_fr_ntt(pm_ctx* ctx, const uint64_t* in, size_t in_len, uint64_t* out, uint32_t log_n,
+              uint32_t flags);
+
+/* `batch` independent transforms of the same size (a prover round issues 4-6 of them).
+ * Vector b starts at in + 4*b*in_stride / out + 4*b*out_stride (strides in Fr elements). */
+int pm_fr_ntt_batch(pm_ctx* ctx, const uint64_t* in, size_t in_len, size_t in_stride,
+                    uint64_t* out, size_t out_stride, uint32_t log_n, uint32_t batch,
+                    uint32_t flags);
+
+/* Same transform on DEVICE-resident data (addresses on ctx's GPU), asynchronous on
+ * `hip_stream` (a hipStream_t; NULL = the context's own stream).  d_in == d_out allowed. */
+int pm_fr_ntt_dev(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
+                  size_t out_stride, uint32_t log_n, uint32_t batch, uint32_t flags,
+                  void* hip_stream);
+
+/* ---- KZG commit: G1 MSM ---------------------------------------------------------------- */
+
+/* Upload n affine bases (CommitKey::powers_of_g) once; they stay resident in HBM. */
+int pm_g1_bases_upload(pm_ctx* ctx, const uint64_t* xy, size_t n, pm_bases** out);
+void pm_g1_bases_free(pm_ctx* ctx, pm_bases* bases);
+size_t pm_g1_bases_len(const pm_bases* bases);
+
+/* out = sum_{i<n} scalars[i] * bases[i]   (msm_variable_base(&bases[..n], scalars)).
+ * Host scalars, n x 4 limbs.  n == 0 gives the identity. */
+int pm_g1_msm(pm_ctx* ctx, const pm_bases* bases, size_t n, const uint64_t* scalars,
+              uint32_t scalar_form, uint64_t out_xyz[18]);
+
+/* Device-resident scalars; uses bases[offset .. offset+n) -- the shard primitive for
+ * multi-GPU runs (each rank owns a slice of the points, then pm_g1_fold after all-gather).
+ * Blocks until the 144-byte result is on the host. */
+int pm_g1_msm_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n,
+                  const void* d_scalars, uint32_t scalar_form, uint64_t out_xyz[18],
+                  void* hip_stream);
+
+/* out = sum of k projective points (the group-law "all-reduce" after an all-gather). Host. */
+int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]);
+
+/* Projective (homogeneous X/Z, Y/Z) -> affine; *is_identity = 1 and xy = 0 for infinity. */
+int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_identity);
+
+/* ---- introspection / tuning (not needed by the prover) --------------------------------- */
+
+/* Number of kernel launches and the Stockham radices the library will use for 2^log_n. */
+int pm_ntt_plan(uint32_t log_n, uint32_t radix_log2[4], uint32_t* n_passes);
+/* Override tunables: "msm_window_bits", "ntt_tile_log".  Returns PM_ERR_BAD_ARG if unknown. */
+int pm_set_option(pm_ctx* ctx, const char* key, long value);
+/* Elementwise field kernels used by the parity tests: op 0 = Fr mul, 1 = Fr add, 2 = Fr sub,
+ * 3 = Fp mul, 4 = Fp add, 5 = Fp sub.  Host pointers, n elements. */
+int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                     size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_MI355X_H */

@@ -1,0 +1,75 @@
+"""ctypes declarations of the C ABI in ``include/plonk_mi355x.h`` (one entry per export)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplonk_mi355x.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+# name -> (restype, argtypes); must list every function the header declares
+SIGNATURES = {
+    "pm_version": (C.c_char_p, []),
+    "pm_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pm_shutdown": (None, [C.c_void_p]),
+    "pm_last_error": (C.c_char_p, [C.c_void_p]),
+    "pm_sync": (C.c_int, [C.c_void_p]),
+    "pm_domain_info": (C.c_int, [C.c_uint32, u64p, u64p, u64p]),
+    "pm_domain_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pm_fr_ntt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_uint32, C.c_uint32]),
+    "pm_fr_ntt_batch": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, C.c_size_t,
+                                  C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pm_fr_ntt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "pm_g1_bases_upload": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pm_g1_bases_free": (None, [C.c_void_p, C.c_void_p]),
+    "pm_g1_bases_len": (C.c_size_t, [C.c_void_p]),
+    "pm_g1_msm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_uint32, u64p]),
+    "pm_g1_msm_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                C.c_uint32, u64p, C.c_void_p]),
+    "pm_g1_fold": (C.c_int, [u64p, C.c_size_t, u64p]),
+    "pm_g1_to_affine": (C.c_int, [u64p, u64p, C.POINTER(C.c_int)]),
+    "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
+    "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    "pm_test_field_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
+}
+
+PM_OK = 0
+PM_ERR_BAD_ARG = -1
+PM_ERR_DOMAIN_TOO_LARGE = -2
+PM_ERR_OOM = -3
+PM_ERR_HIP = -4
+PM_ERR_NO_DEVICE = -5
+PM_ERR_LENGTH = -6
+
+NTT_INVERSE = 1
+NTT_COSET = 2
+SCALAR_MONTGOMERY = 0
+SCALAR_CANONICAL = 1
+
+_lib = None
+
+
+class BackendMissing(RuntimeError):
+    """The HIP extension is not built / not loadable.  There is no CPU fallback."""
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree HIP library and bind every symbol.  Fails loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C plonk-prototype_amd/csrc`).  This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared export
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

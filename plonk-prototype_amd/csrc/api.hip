@@ -1,0 +1,149 @@
+// Context management, error reporting and the elementwise field-op test hooks.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "context.h"
+#include "fields.cuh"
+
+namespace pm {
+
+int set_err(pm_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes) {
+  if (b.bytes >= bytes && b.ptr) return PM_OK;
+  if (b.ptr) {
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PM_HIP(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+  }
+  PM_HIP(ctx, hipMalloc(&b.ptr, bytes));
+  b.bytes = bytes;
+  return PM_OK;
+}
+
+template <class P, int OP>
+__global__ void field_op_kernel(const u32x4* a, const u32x4* b, u32x4* out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int V = P::N / 4;
+  Fe<P> x = fe_load<P>(a + V * i), y = fe_load<P>(b + V * i), r;
+  // operands are canonical ABI-Montgomery values (R = 2^(32 NS)); the device product divides by
+  // R' = 2^(W N), so rescale by 2^(W N - 32 NS) to return the ABI-form product
+  if (OP == 0) r = fe_abi_to_dev<P>(fe_mul<P>(x, y));
+  if (OP == 1) r = fe_add<P>(x, y);
+  if (OP == 2) r = fe_mul<P>(fe_sub<P, 2, 1>(x, y), fe_one<P>());
+  fe_store<P>(out + V * i, r);
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" const char* pm_version(void) { return "plonk_mi355x 0.1 (gfx950)"; }
+
+extern "C" int pm_init(int device_id, pm_ctx** out) {
+  if (!out) return PM_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count)
+    return PM_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return PM_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PM_ERR_NO_DEVICE;  // gfx950 code objects only
+  if (hipSetDevice(device_id) != hipSuccess) return PM_ERR_HIP;
+  pm_ctx* ctx = new pm_ctx();
+  ctx->device = device_id;
+  ctx->num_cus = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return PM_ERR_HIP;
+  }
+  *out = ctx;
+  return PM_OK;
+}
+
+extern "C" void pm_shutdown(pm_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (int d = 0; d < 2; ++d) {
+    for (auto& kv : ctx->step_tw[d]) hipFree(kv.second);
+    for (auto& kv : ctx->domain[d]) {
+      hipFree(kv.second.tw_hi);
+      hipFree(kv.second.tw_lo);
+      hipFree(kv.second.cs_hi);
+      hipFree(kv.second.cs_lo);
+    }
+  }
+  for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws,
+                          &ctx->msm_scalars})
+    if (b->ptr) hipFree(b->ptr);
+  if (ctx->msm_host_pinned) hipHostFree(ctx->msm_host_pinned);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* pm_last_error(const pm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int pm_sync(pm_ctx* ctx) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PM_OK;
+}
+
+extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
+  if (!ctx || !key) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!strcmp(key, "msm_window_bits")) {
+    if (value != 0 && (value < 4 || value > 20)) return set_err(ctx, PM_ERR_BAD_ARG, "msm_window_bits out of range");
+    ctx->opt_msm_window_bits = value;
+    return PM_OK;
+  }
+  if (!strcmp(key, "ntt_tile_log")) {
+    if (value != 11 && value != 12) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_tile_log must be 11 or 12");
+    ctx->opt_ntt_tile_log = value;
+    return PM_OK;
+  }
+  return set_err(ctx, PM_ERR_BAD_ARG, std::string("unknown option ") + key);
+}
+
+extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b,
+                                uint64_t* out, size_t n) {
+  if (!ctx || !a || !b || !out) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (op < 0 || op > 5) return set_err(ctx, PM_ERR_BAD_ARG, "op");
+  if (n == 0) return PM_OK;
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t esz = op < 3 ? 32 : 48;
+  void *da, *db, *dc;
+  PM_HIP(ctx, hipMalloc(&da, n * esz));
+  PM_HIP(ctx, hipMalloc(&db, n * esz));
+  PM_HIP(ctx, hipMalloc(&dc, n * esz));
+  PM_HIP(ctx, hipMemcpyAsync(da, a, n * esz, hipMemcpyHostToDevice, ctx->stream));
+  PM_HIP(ctx, hipMemcpyAsync(db, b, n * esz, hipMemcpyHostToDevice, ctx->stream));
+  dim3 g((unsigned)((n + 255) / 256)), blk(256);
+  const u32x4 *pa = (const u32x4*)da, *pb = (const u32x4*)db;
+  u32x4* pc = (u32x4*)dc;
+  switch (op) {
+    case 0: hipLaunchKernelGGL((field_op_kernel<FrP, 0>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 1: hipLaunchKernelGGL((field_op_kernel<FrP, 1>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 2: hipLaunchKernelGGL((field_op_kernel<FrP, 2>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 3: hipLaunchKernelGGL((field_op_kernel<FpP, 0>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 4: hipLaunchKernelGGL((field_op_kernel<FpP, 1>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 5: hipLaunchKernelGGL((field_op_kernel<FpP, 2>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+  }
+  PM_HIP(ctx, hipGetLastError());
+  PM_HIP(ctx, hipMemcpyAsync(out, dc, n * esz, hipMemcpyDeviceToHost, ctx->stream));
+  PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(da);
+  hipFree(db);
+  hipFree(dc);
+  return PM_OK;
+}

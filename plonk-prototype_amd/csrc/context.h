@@ -1,0 +1,69 @@
+// Library context: one GPU, one stream, cached domain tables, reusable workspaces.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/plonk_mi355x.h"
+
+namespace pm {
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct NttDomainTables {  // per (log_n, direction)
+  void* tw_hi = nullptr;
+  void* tw_lo = nullptr;
+  void* cs_hi = nullptr;
+  void* cs_lo = nullptr;
+  unsigned lh = 0;
+};
+
+}  // namespace pm
+
+struct pm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+  // NTT caches
+  std::map<unsigned, void*> step_tw[2];                 // [dir][S] -> device table
+  std::map<unsigned, pm::NttDomainTables> domain[2];    // [dir][log_n]
+  pm::DeviceBuffer ntt_tmp[2];
+  pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
+  // MSM workspaces
+  pm::DeviceBuffer msm_ws;
+  pm::DeviceBuffer msm_scalars;
+  void* msm_host_pinned = nullptr;
+  size_t msm_host_pinned_bytes = 0;
+  // tunables
+  long opt_msm_window_bits = 0;  // 0 = auto
+  long opt_ntt_tile_log = 11;
+  int num_cus = 256;
+};
+
+struct pm_bases {
+  void* d_xy = nullptr;  // n x 96 bytes, affine Montgomery, (0,0) = identity
+  size_t n = 0;
+  int device = 0;
+};
+
+namespace pm {
+
+int set_err(pm_ctx* ctx, int code, const std::string& msg);
+int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
+
+#define PM_HIP(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return pm::set_err(ctx, _e == hipErrorOutOfMemory ? PM_ERR_OOM : PM_ERR_HIP,          \
+                         std::string(#call) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+}  // namespace pm

@@ -1,0 +1,377 @@
+// BLS12-381 Fr / Fp Montgomery arithmetic for gfx950 (device side), carry-free form.
+//
+// Why unsaturated limbs.  Measured on MI355X (tools/ubench.hip, profiles/r01_ubench.txt):
+// v_mad_u64_u32 issues at the same ~4.4 cycles per wave-instruction as v_add_u32 -- 32-bit
+// integer multiply is full rate on CDNA4 -- but gfx950 needs two wait states between a VALU
+// that writes a carry (VCC / SGPR pair) and the VALU that consumes it (hipcc pads every
+// v_addc with `s_nop 1`).  A classic saturated 8 x 32-bit Montgomery product is one mad plus
+// one dependent v_addc per limb product, i.e. a hazard on every second instruction.  With
+// radix 2^29 (Fr, 9 limbs) / 2^28 (Fp, 14 limbs) a 64-bit column accumulator absorbs every
+// limb product of a column without overflow: the product is pure `acc += (u64)a*b`
+// (v_mad_u64_u32, no carry-out), additions are limb-wise, and no instruction ever reads a
+// carry flag.  Plain C++ -- no inline asm, the compiler schedules everything.
+//
+// Value domain: elements are kept in a redundant range (value < V*m, limbs < B*2^W); the
+// Montgomery radix R = 2^(W*N) exceeds the modulus by 2^6 (Fr) / 2^11 (Fp), so
+// fe_mul(a, b) < a*b/R + m lands below 2m without any conditional subtraction for every
+// operand bound used in this library.  Canonical form (the ABI: saturated 32-bit limbs,
+// fully reduced, bit-identical to dusk_bls12_381::{Scalar, Fp} memory, ref:Cargo.toml:20;
+// Scalar used at ref:allocated_scalar.rs:19) exists only at kernel boundaries:
+// fe_unpack() on load, fe_canon_pack() on store.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pm {
+
+typedef uint32_t u32;
+typedef unsigned long long u64;
+
+#define PM_DEV __device__ __forceinline__
+#define PM_HD __host__ __device__ constexpr
+
+// ------------------------------------------------------------------ parameters
+// SAT[] = modulus in saturated 32-bit limbs; everything else is derived at compile time.
+struct FrP {
+  static constexpr int W = 29;   // limb bits
+  static constexpr int N = 9;    // limbs, R = 2^261
+  static constexpr int NS = 8;   // saturated 32-bit limbs at the ABI
+  static constexpr u32 SAT[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+};
+struct FpP {
+  static constexpr int W = 28;
+  static constexpr int N = 14;   // R = 2^392
+  static constexpr int NS = 12;
+  static constexpr u32 SAT[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu,
+                                  0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u,
+                                  0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+};
+
+template <int N>
+struct Limbs {
+  u32 v[N];
+};
+
+// bits [lo, lo+w) of a saturated little-endian limb array
+template <int NS>
+PM_HD u32 sat_bits(const u32 (&s)[NS], int lo, int w) {
+  u64 x = 0;
+  int i = lo / 32, sh = lo % 32;
+  if (i < NS) x = s[i] >> sh;
+  if (i + 1 < NS && sh) x |= (u64)s[i + 1] << (32 - sh);
+  return (u32)(x & ((w >= 32) ? 0xffffffffull : ((1ull << w) - 1)));
+}
+
+template <class P>
+struct Consts {
+  static constexpr int W = P::W, N = P::N, NS = P::NS;
+  static constexpr u32 MASK = (1u << W) - 1;
+  // modulus in radix 2^W
+  static PM_HD Limbs<N> mod_limbs() {
+    Limbs<N> r{};
+    for (int i = 0; i < N; ++i) r.v[i] = sat_bits<NS>(P::SAT, i * W, W);
+    return r;
+  }
+  // -m^-1 mod 2^W (Newton)
+  static PM_HD u32 neg_inv() {
+    u32 m0 = sat_bits<NS>(P::SAT, 0, W);
+    u32 x = 1;
+    for (int i = 0; i < 6; ++i) x = x * (2u - m0 * x);
+    return (0u - x) & MASK;
+  }
+  // k*m in radix 2^W (normalised; top limb unbounded)
+  static PM_HD Limbs<N> k_mod(u32 k) {
+    Limbs<N> m = mod_limbs(), r{};
+    u64 c = 0;
+    for (int i = 0; i < N; ++i) {
+      u64 t = (u64)m.v[i] * k + c;
+      r.v[i] = (i == N - 1) ? (u32)t : (u32)(t & MASK);
+      c = t >> W;
+    }
+    return r;
+  }
+  // 2^e mod m in radix 2^W (compile-time double-and-reduce)
+  static PM_HD Limbs<N> pow2_mod(int e) {
+    Limbs<N> m = mod_limbs(), x{};
+    x.v[0] = 1;
+    for (int it = 0; it < e; ++it) {
+      u32 c = 0;
+      for (int i = 0; i < N; ++i) {  // x = 2x (normalised; the top limb keeps the overflow)
+        u32 t = (x.v[i] << 1) | c;
+        c = (i == N - 1) ? 0 : (t >> W);
+        x.v[i] = (i == N - 1) ? t : (t & MASK);
+      }
+      bool ge = true;  // x >= m ?
+      for (int i = N - 1; i >= 0; --i) {
+        if (x.v[i] != m.v[i]) {
+          ge = x.v[i] > m.v[i];
+          break;
+        }
+      }
+      if (ge) {
+        u32 bw = 0;
+        for (int i = 0; i < N; ++i) {
+          u32 t = x.v[i] - m.v[i] - bw;
+          bw = (i == N - 1) ? 0 : ((t >> W) & 1);
+          x.v[i] = (i == N - 1) ? t : (t & MASK);
+        }
+      }
+    }
+    return x;
+  }
+  // k*m with every limb but the top biased by 2^(W+E) - 2^E so that a limb-wise
+  // `a + bias - b` cannot go negative for b limbs < 2^(W+E) - 2^E (top limb: < top of k*m - 2^E)
+  static PM_HD Limbs<N> sub_bias(u32 k, int E) {
+    Limbs<N> r = k_mod(k);
+    for (int i = 0; i < N - 1; ++i) {
+      r.v[i] += (1u << (W + E));
+      r.v[i + 1] -= (1u << E);
+    }
+    return r;
+  }
+};
+
+template <class P>
+struct Fe {
+  u32 l[P::N];
+};
+typedef Fe<FrP> Fr;
+typedef Fe<FpP> Fp;
+
+// ------------------------------------------------------------------ trivial ops
+template <class P>
+PM_DEV Fe<P> fe_zero() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::N; ++i) r.l[i] = 0;
+  return r;
+}
+// limb-wise sum: value and limb bounds add
+template <class P>
+PM_DEV Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::N; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+// a - b + K*m.  Requires b limbs < 2^(W+E) - 2^E and b's top limb < top(K*m) - 2^E.
+// Result: value < a + K*m, limbs < a + 2^(W+E) + 2^W.
+template <class P, int K, int E>
+PM_DEV Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+  constexpr Limbs<P::N> bias = Consts<P>::sub_bias(K, E);
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::N; ++i) r.l[i] = a.l[i] + (bias.v[i] - b.l[i]);
+  return r;
+}
+// one parallel carry step: limbs < 2^32 in -> limbs < 2^W + 2^(32-W) out (top limb keeps the rest)
+template <class P>
+PM_DEV Fe<P> fe_norm(const Fe<P>& a) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  Fe<P> r;
+  r.l[0] = a.l[0] & MASK;
+#pragma unroll
+  for (int i = 1; i < N - 1; ++i) r.l[i] = (a.l[i] & MASK) + (a.l[i - 1] >> W);
+  r.l[N - 1] = a.l[N - 1] + (a.l[N - 2] >> W);
+  return r;
+}
+// full sequential carry: every limb but the top < 2^W
+template <class P>
+PM_DEV Fe<P> fe_norm_full(const Fe<P>& a) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  Fe<P> r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    u32 t = a.l[i] + c;
+    r.l[i] = t & MASK;
+    c = t >> W;
+  }
+  r.l[N - 1] = a.l[N - 1] + c;
+  return r;
+}
+
+// ------------------------------------------------------------------ Montgomery product
+// Column-wise (product scanning) with a single 64-bit accumulator and no carries.
+// Requires  N * max(a limb) * max(b limb) + (N-1) * 2^(2W) + 2^(64-W) < 2^64, i.e. with
+// b normalised (limbs <= 2^W + 8):  a limbs < 6 * 2^29 (Fr) / < 13 * 2^28 (Fp).
+// Result: limbs < 2^W (normalised), value < a*b/R + m.
+template <class P>
+PM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q[N];
+  Fe<P> t;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (u64)q[i] * M.v[k - i];
+    if (M.v[0] == 1u) {  // Fr: m = 1 mod 2^W, -m^-1 = -1
+      q[k] = (0u - (u32)acc) & MASK;
+      acc += q[k];
+    } else {
+      q[k] = ((u32)acc * NINV) & MASK;
+      acc += (u64)q[k] * M.v[0];
+    }
+    acc >>= W;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) acc += (u64)q[i] * M.v[k - i];
+    t.l[k - N] = (u32)acc & MASK;
+    acc >>= W;
+  }
+  t.l[N - 1] = (u32)acc;
+  return t;
+}
+template <class P>
+PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
+  return fe_mul<P>(a, a);
+}
+
+// compile-time constant 2^e mod m as an element (canonical limbs)
+template <class P>
+PM_DEV Fe<P> fe_pow2(int e_is_constexpr_at_call_site) = delete;
+template <class P, int E>
+PM_DEV Fe<P> fe_pow2() {
+  constexpr Limbs<P::N> c = Consts<P>::pow2_mod(E);
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::N; ++i) r.l[i] = c.v[i];
+  return r;
+}
+// 1 in the device Montgomery form (R' = 2^(W N)): multiplying by it reduces without changing the value
+template <class P>
+PM_DEV Fe<P> fe_one() {
+  return fe_pow2<P, P::W * P::N>();
+}
+// x in ABI Montgomery form (R = 2^(32 NS)) <-> device form (R' = 2^(W N)):  x * 2^(+-(W N - 32 NS))
+template <class P>
+PM_DEV Fe<P> fe_abi_to_dev(const Fe<P>& a) {  // multiply by 2^(WN - 32NS): fe_mul by 2^(2WN - 32NS)
+  return fe_mul<P>(a, fe_pow2<P, 2 * P::W * P::N - 32 * P::NS>());
+}
+template <class P>
+PM_DEV Fe<P> fe_dev_to_abi(const Fe<P>& a) {  // multiply by 2^(32NS - WN): fe_mul by 2^(32NS)
+  return fe_mul<P>(a, fe_pow2<P, 32 * P::NS>());
+}
+
+// ------------------------------------------------------------------ canonical boundary
+// saturated canonical (NS x 32 bit) -> radix 2^W, normalised
+template <class P>
+PM_DEV Fe<P> fe_unpack(const u32* s) {
+  constexpr int N = P::N, W = P::W, NS = P::NS;
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int lo = i * W, j = lo / 32, sh = lo % 32;
+    u32 x = 0;
+    if (j < NS) x = s[j] >> sh;
+    if (j + 1 < NS && sh + W > 32) x |= s[j + 1] << (32 - sh);
+    r.l[i] = x & Consts<P>::MASK;
+  }
+  return r;
+}
+// fully normalised limbs (value < 2^(32 NS)) -> saturated
+template <class P>
+PM_DEV void fe_pack_raw(u32* s, const Fe<P>& a) {
+  constexpr int N = P::N, W = P::W, NS = P::NS;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    // bits [32j, 32j+32) come from limbs i0 = floor(32j / W) and following
+    const int lo = 32 * j;
+    u32 x = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int l0 = i * W;  // limb i covers [l0, l0 + W) (top limb: beyond)
+      if (l0 < lo + 32 && l0 + 32 > lo) {
+        if (l0 >= lo)
+          x |= a.l[i] << (l0 - lo);
+        else
+          x |= a.l[i] >> (lo - l0);
+      }
+    }
+    s[j] = x;
+  }
+}
+// value < 2m (limbs < 2^32) -> canonical saturated limbs
+template <class P>
+PM_DEV void fe_canon_pack(u32* s, const Fe<P>& a) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  Fe<P> x = fe_norm_full<P>(a);
+  // d = x - m with a signed borrow chain
+  Fe<P> d;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    int32_t t = (int32_t)x.l[i] - (int32_t)M.v[i] + c;
+    d.l[i] = (u32)t & MASK;
+    c = t >> W;  // arithmetic shift: 0 or -1
+  }
+  int32_t top = (int32_t)x.l[N - 1] - (int32_t)M.v[N - 1] + c;
+  d.l[N - 1] = (u32)top;
+  const bool neg = top < 0;  // x < m: keep x
+#pragma unroll
+  for (int i = 0; i < N; ++i) x.l[i] = neg ? x.l[i] : d.l[i];
+  fe_pack_raw<P>(s, x);
+}
+
+template <class P>
+PM_DEV Fe<P> fe_const_sat(const u32* s) {  // uniform saturated constant -> limbs
+  return fe_unpack<P>(s);
+}
+
+// exact zero test for a value known to be < 2m with any limb slack: canonicalise first
+template <class P>
+PM_DEV bool fe_is_zero_canon(const Fe<P>& a) {
+  u32 s[P::NS];
+  fe_canon_pack<P>(s, a);
+  u32 x = 0;
+#pragma unroll
+  for (int i = 0; i < P::NS; ++i) x |= s[i];
+  return x == 0;
+}
+
+// ------------------------------------------------------------------ 16-byte vector IO
+struct __attribute__((aligned(16))) u32x4 {
+  u32 x, y, z, w;
+};
+
+// canonical element in memory (NS/4 x 16 bytes) -> limbs
+template <class P>
+PM_DEV Fe<P> fe_load(const void* p) {
+  u32 s[P::NS];
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < P::NS / 4; ++i) {
+    u32x4 v = q[i];
+    s[4 * i] = v.x;
+    s[4 * i + 1] = v.y;
+    s[4 * i + 2] = v.z;
+    s[4 * i + 3] = v.w;
+  }
+  return fe_unpack<P>(s);
+}
+// limbs (value < 2m) -> canonical element in memory
+template <class P>
+PM_DEV void fe_store(void* p, const Fe<P>& a) {
+  u32 s[P::NS];
+  fe_canon_pack<P>(s, a);
+  u32x4* q = reinterpret_cast<u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < P::NS / 4; ++i) q[i] = u32x4{s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]};
+}
+
+}  // namespace pm

@@ -1,0 +1,369 @@
+// Host side of the Fr NTT: domain tables, pass planning, launches, and the pm_fr_ntt* ABI.
+// Mirrors dusk_plonk::fft::EvaluationDomain (dusk-plonk 0.8.2, ref:Cargo.toml:19):
+//   new()      -> domain_constants()  (group_gen = ROOT_OF_UNITY^(2^(32-log_n)), size_inv, ...)
+//   fft/ifft/coset_fft/coset_ifft -> ntt_run() with PM_NTT_INVERSE / PM_NTT_COSET
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "context.h"
+#include "host_field.h"
+#include "ntt_kernels.cuh"
+
+namespace pm {
+
+using host::HFr;
+
+// ------------------------------------------------------------------ kernel table
+typedef void (*pass_fn)(const NttPassArgs, const NttConsts);
+enum Role { ROLE_SINGLE = 0, ROLE_FIRST = 1, ROLE_MIDDLE = 2, ROLE_LAST = 3 };
+struct PassEntry {
+  int S, LT, role;
+  pass_fn fn;
+};
+// (S, LT): LT = 0 single-pass kernels; multi-pass tiles of 2^11 (LT = 11 - S) or 2^12 elements
+#define PM_SINGLE(X) X(3, 0) X(4, 0) X(5, 0) X(6, 0) X(7, 0) X(8, 0) X(9, 0) X(10, 0)
+#define PM_MULTI(X) X(5, 6) X(6, 5) X(7, 4) X(8, 3) X(9, 2) X(10, 1) X(8, 4) X(9, 3) X(10, 2)
+static const PassEntry kPassTable[] = {
+#define X(S, LT) {S, LT, ROLE_SINGLE, ntt_pass_kernel<S, LT, false, false, false>},
+    PM_SINGLE(X)
+#undef X
+#define X(S, LT)                                                      \
+  {S, LT, ROLE_FIRST, ntt_pass_kernel<S, LT, true, false, true>},     \
+      {S, LT, ROLE_MIDDLE, ntt_pass_kernel<S, LT, false, true, true>}, \
+      {S, LT, ROLE_LAST, ntt_pass_kernel<S, LT, false, true, false>},
+        PM_MULTI(X)
+#undef X
+};
+static pass_fn find_pass(int S, int LT, int role) {
+  for (const PassEntry& e : kPassTable)
+    if (e.S == S && e.LT == LT && e.role == role) return e.fn;
+  return nullptr;
+}
+
+struct Plan {
+  int npass = 0;
+  int S[4] = {0, 0, 0, 0};
+  int LT[4] = {0, 0, 0, 0};
+};
+static Plan make_plan(unsigned log_n, int tile_log) {
+  Plan p;
+  if (log_n < 3) return p;  // tiny kernel
+  if (log_n <= 10) {
+    p.npass = 1;
+    p.S[0] = (int)log_n;
+    return p;
+  }
+  p.npass = (int)((log_n + 9) / 10);
+  int base = (int)log_n / p.npass, extra = (int)log_n % p.npass;
+  for (int i = 0; i < p.npass; ++i) {
+    p.S[i] = base + (i < extra ? 1 : 0);
+    int lt = tile_log - p.S[i];
+    if (p.S[i] < 8) lt = 11 - p.S[i];  // 2^12-element tiles exist for S >= 8 only
+    lt = std::min(lt, (int)log_n - p.S[i]);
+    p.LT[i] = lt;
+  }
+  return p;
+}
+
+// ------------------------------------------------------------------ host constants
+static HFr fr_pow2k(HFr x, unsigned k) {  // x^(2^k)
+  for (unsigned i = 0; i < k; ++i) x = host::mul(x, x, host::FR());
+  return x;
+}
+static HFr domain_gen(unsigned log_n) { return fr_pow2k(host::fr_root_of_unity(), 32 - log_n); }
+// ABI Montgomery form (x * 2^256) -> device form (x * 2^261) as 9 x 29-bit limbs
+static void to_limbs(u32* dst, HFr v) {
+  for (int i = 0; i < 5; ++i) v = host::add(v, v, host::FR());
+  for (int i = 0; i < 9; ++i) {
+    const int lo = 29 * i, j = lo / 64, sh = lo % 64;
+    u64 x = v.l[j] >> sh;
+    if (sh + 29 > 64 && j + 1 < 4) x |= v.l[j + 1] << (64 - sh);
+    dst[i] = (u32)(x & ((1u << 29) - 1));
+  }
+}
+
+static int build_pow_table(pm_ctx* ctx, void** out, const HFr& base, const HFr& mult, u32 count,
+                           u32 stride, hipStream_t st) {
+  PM_HIP(ctx, hipMalloc(out, (size_t)count * 48));
+  NttConsts c;
+  memset(&c, 0, sizeof c);
+  to_limbs(c.w8[0], base);
+  to_limbs(c.scale, mult);
+  to_limbs(c.one, host::one(host::FR()));
+  hipLaunchKernelGGL(pow_table_kernel, dim3((count + 255) / 256), dim3(256), 0, st, (u32x4*)*out, c,
+                     count, stride);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
+}
+
+static int get_step_table(pm_ctx* ctx, int dir, unsigned S, void** out, hipStream_t st) {
+  auto it = ctx->step_tw[dir].find(S);
+  if (it != ctx->step_tw[dir].end()) {
+    *out = it->second;
+    return PM_OK;
+  }
+  HFr wR = domain_gen(S);
+  if (dir) wR = host::inv(wR, host::FR());
+  u32 total = (u32)step_tw_total((int)S);
+  void* d = nullptr;
+  PM_HIP(ctx, hipMalloc(&d, (size_t)total * 48));
+  NttConsts c;
+  memset(&c, 0, sizeof c);
+  to_limbs(c.w8[0], wR);
+  to_limbs(c.one, host::one(host::FR()));
+  hipLaunchKernelGGL(step_tw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (u32x4*)d, c, S);
+  PM_HIP(ctx, hipGetLastError());
+  ctx->step_tw[dir][S] = d;
+  *out = d;
+  return PM_OK;
+}
+
+static int get_domain_tables(pm_ctx* ctx, int dir, unsigned log_n, bool need_coset,
+                             NttDomainTables** out, hipStream_t st) {
+  NttDomainTables& t = ctx->domain[dir][log_n];
+  const host::Field<4>& F = host::FR();
+  t.lh = (log_n + 1) / 2;
+  const u32 n_lo = 1u << t.lh, n_hi = 1u << (log_n - t.lh);
+  if (!t.tw_lo) {
+    HFr w = domain_gen(log_n);
+    if (dir) w = host::inv(w, F);
+    int rc = build_pow_table(ctx, &t.tw_lo, w, host::one(F), n_lo, 1, st);
+    if (rc) return rc;
+    rc = build_pow_table(ctx, &t.tw_hi, w, host::one(F), n_hi, n_lo, st);
+    if (rc) return rc;
+  }
+  if (need_coset && !t.cs_lo) {
+    HFr g = host::from_u64(host::FR_GENERATOR, F);
+    HFr mult = host::one(F);
+    if (dir) {
+      g = host::inv(g, F);
+      mult = host::inv(host::from_u64((u64)1 << log_n, F), F);  // size_inv folded into cs_hi
+    }
+    int rc = build_pow_table(ctx, &t.cs_lo, g, host::one(F), n_lo, 1, st);
+    if (rc) return rc;
+    rc = build_pow_table(ctx, &t.cs_hi, g, mult, n_hi, n_lo, st);
+    if (rc) return rc;
+  }
+  *out = &t;
+  return PM_OK;
+}
+
+static void fill_consts(NttConsts& c, int dir, unsigned log_n) {
+  const host::Field<4>& F = host::FR();
+  HFr w8 = domain_gen(3);
+  if (dir) w8 = host::inv(w8, F);
+  HFr w = w8;
+  for (int i = 0; i < 3; ++i) {
+    to_limbs(c.w8[i], w);
+    w = host::mul(w, w8, F);
+  }
+  to_limbs(c.one, host::one(F));
+  if (dir)
+    to_limbs(c.scale, host::inv(host::from_u64((u64)1 << log_n, F), F));
+  else
+    to_limbs(c.scale, host::one(F));
+}
+
+// ------------------------------------------------------------------ execution
+int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
+            size_t out_stride, unsigned log_n, unsigned batch, unsigned flags, hipStream_t st) {
+  if (log_n >= host::FR_TWO_ADICITY)
+    return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
+  const size_t n = (size_t)1 << log_n;
+  if (in_len > n) return set_err(ctx, PM_ERR_LENGTH, "in_len > 2^log_n");
+  if (batch == 0) return PM_OK;
+  if (batch > 1 && (in_stride < in_len || out_stride < n))
+    return set_err(ctx, PM_ERR_BAD_ARG, "batch strides shorter than the vectors");
+  if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET)) return set_err(ctx, PM_ERR_BAD_ARG, "unknown flags");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  const int dir = (flags & PM_NTT_INVERSE) ? 1 : 0;
+  const bool coset = (flags & PM_NTT_COSET) != 0;
+
+  if (log_n == 0) {  // size-1 domain: identity (w = 1, size_inv = 1, g^0 = 1); zero if in_len == 0
+    for (unsigned b = 0; b < batch; ++b) {
+      char* o = (char*)d_out + b * out_stride * 32;
+      if (in_len == 0) {
+        PM_HIP(ctx, hipMemsetAsync(o, 0, 32, st));
+      } else if (o != (const char*)d_in + b * in_stride * 32) {
+        PM_HIP(ctx, hipMemcpyAsync(o, (const char*)d_in + b * in_stride * 32, 32,
+                                   hipMemcpyDeviceToDevice, st));
+      }
+    }
+    return PM_OK;
+  }
+
+  NttDomainTables* dt = nullptr;
+  int rc = get_domain_tables(ctx, dir, log_n, coset, &dt, st);
+  if (rc) return rc;
+  NttConsts kc;
+  fill_consts(kc, dir, log_n);
+
+  NttPassArgs a;
+  memset(&a, 0, sizeof a);
+  a.tw_hi = (const u32x4*)dt->tw_hi;
+  a.tw_lo = (const u32x4*)dt->tw_lo;
+  a.cs_hi = (const u32x4*)dt->cs_hi;
+  a.cs_lo = (const u32x4*)dt->cs_lo;
+  a.log_n = log_n;
+  a.lh = dt->lh;
+
+  const u32 pre = (coset && !dir) ? PASS_PRE_COSET : 0u;
+  const u32 post = (coset && dir) ? PASS_POST_COSET : 0u;
+
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log);
+  if (plan.npass == 0) {
+    a.in = (const u32x4*)d_in;
+    a.out = (u32x4*)d_out;
+    a.batch_stride_in = in_stride;
+    a.batch_stride_out = out_stride;
+    a.in_len = (u32)in_len;
+    a.flags = pre | post;
+    hipLaunchKernelGGL(ntt_tiny_kernel, dim3(1, batch), dim3(64), 0, st, a, kc);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+  }
+
+  // buffers: pass i reads src, writes (last ? out : tmp[i & 1]); a pass never runs in place
+  const bool inplace = (d_in == d_out);
+  const int ntmp = plan.npass - 1 + ((plan.npass == 1 && inplace) ? 1 : 0);
+  for (int i = 0; i < std::min(ntmp, 2); ++i) {
+    rc = ensure_buffer(ctx, ctx->ntt_tmp[i], (size_t)batch * n * 36);
+    if (rc) return rc;
+  }
+  const void* src = d_in;
+  unsigned log_ns = 0;
+  a.wide_total = (unsigned long long)batch * n;
+  for (int i = 0; i < plan.npass; ++i) {
+    const bool last = (i == plan.npass - 1);
+    const int S = plan.S[i], LT = plan.LT[i];
+    // intermediate vectors are 9-limb "wide" planes in ntt_tmp[]; only a single-pass
+    // in-place transform needs a canonical bounce buffer (ntt_tmp[0]) plus a copy
+    void* dst = (last && !(plan.npass == 1 && inplace)) ? d_out : ctx->ntt_tmp[i & 1].ptr;
+    const int role = plan.npass == 1 ? ROLE_SINGLE : (i == 0 ? ROLE_FIRST : (last ? ROLE_LAST : ROLE_MIDDLE));
+    pass_fn fn = find_pass(S, LT, role);
+    if (!fn) return set_err(ctx, PM_ERR_BAD_ARG, "no kernel for this pass shape");
+    void* stw = nullptr;
+    rc = get_step_table(ctx, dir, (unsigned)S, &stw, st);
+    if (rc) return rc;
+    a.in = src;
+    a.out = dst;
+    a.step_tw = (const u32x4*)stw;
+    a.batch_stride_in = in_stride;
+    a.batch_stride_out = (plan.npass == 1 && inplace) ? n : out_stride;
+    a.in_len = (u32)in_len;
+    a.log_ns = log_ns;
+    a.flags = (i == 0 ? pre : 0u) | (last ? post : 0u);
+    const unsigned threads = std::max(64u, (1u << (S + LT)) / 8);
+    const size_t lds = pass_lds_bytes(S, LT);
+    if (lds > 64 * 1024)
+      PM_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    const unsigned blocks = (unsigned)(n >> (S + LT));
+    hipLaunchKernelGGL(fn, dim3(blocks, batch), dim3(threads), lds, st, a, kc);
+    PM_HIP(ctx, hipGetLastError());
+    src = dst;
+    log_ns += (unsigned)S;
+  }
+  if (plan.npass == 1 && inplace) {
+    PM_HIP(ctx, hipMemcpy2DAsync(d_out, out_stride * 32, ctx->ntt_tmp[0].ptr, n * 32, n * 32, batch,
+                                 hipMemcpyDeviceToDevice, st));
+  }
+  return PM_OK;
+}
+
+}  // namespace pm
+
+// ------------------------------------------------------------------ C ABI
+using namespace pm;
+
+extern "C" int pm_ntt_plan(uint32_t log_n, uint32_t radix_log2[4], uint32_t* n_passes) {
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  Plan p = make_plan(log_n, 11);
+  for (int i = 0; i < 4; ++i) radix_log2[i] = (uint32_t)p.S[i];
+  *n_passes = (uint32_t)p.npass;
+  return PM_OK;
+}
+
+extern "C" int pm_domain_info(uint32_t log_n, uint64_t group_gen[4], uint64_t group_gen_inv[4],
+                              uint64_t size_inv[4]) {
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  const host::Field<4>& F = host::FR();
+  HFr g = domain_gen(log_n);
+  HFr gi = host::inv(g, F);
+  HFr si = host::inv(host::from_u64((u64)1 << log_n, F), F);
+  memcpy(group_gen, g.l, 32);
+  memcpy(group_gen_inv, gi.l, 32);
+  memcpy(size_inv, si.l, 32);
+  return PM_OK;
+}
+
+extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (log_n >= host::FR_TWO_ADICITY)
+    return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  if (log_n == 0) return PM_OK;
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log);
+  for (int dir = 0; dir < 2; ++dir) {
+    NttDomainTables* dt;
+    int rc = get_domain_tables(ctx, dir, log_n, true, &dt, ctx->stream);
+    if (rc) return rc;
+    for (int i = 0; i < plan.npass; ++i) {
+      void* stw;
+      rc = get_step_table(ctx, dir, (unsigned)plan.S[i], &stw, ctx->stream);
+      if (rc) return rc;
+    }
+  }
+  PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PM_OK;
+}
+
+extern "C" int pm_fr_ntt_dev(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride,
+                             void* d_out, size_t out_stride, uint32_t log_n, uint32_t batch,
+                             uint32_t flags, void* hip_stream) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!d_out || (!d_in && in_len)) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  return ntt_run(ctx, d_in, in_len, in_stride, d_out, out_stride, log_n, batch, flags, st);
+}
+
+extern "C" int pm_fr_ntt_batch(pm_ctx* ctx, const uint64_t* in, size_t in_len, size_t in_stride,
+                               uint64_t* out, size_t out_stride, uint32_t log_n, uint32_t batch,
+                               uint32_t flags) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!out || (!in && in_len)) return set_err(ctx, PM_ERR_BAD_ARG, "null pointer");
+  if (log_n >= host::FR_TWO_ADICITY)
+    return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
+  const size_t n = (size_t)1 << log_n;
+  if (in_len > n) return set_err(ctx, PM_ERR_LENGTH, "in_len > 2^log_n");
+  if (batch == 0) return PM_OK;
+  if (batch > 1 && (in_stride < in_len || out_stride < n))
+    return set_err(ctx, PM_ERR_BAD_ARG, "batch strides shorter than the vectors");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t in_elems = std::max<size_t>(in_len, 1);
+  int rc = ensure_buffer(ctx, ctx->io_in, (size_t)batch * in_elems * 32);
+  if (rc) return rc;
+  rc = ensure_buffer(ctx, ctx->io_out, (size_t)batch * n * 32);
+  if (rc) return rc;
+  if (in_len)
+    PM_HIP(ctx, hipMemcpy2DAsync(ctx->io_in.ptr, in_elems * 32, in, in_stride * 32, in_len * 32,
+                                 batch, hipMemcpyHostToDevice, st));
+  rc = ntt_run(ctx, ctx->io_in.ptr, in_len, in_elems, ctx->io_out.ptr, n, log_n, batch, flags, st);
+  if (rc) return rc;
+  PM_HIP(ctx, hipMemcpy2DAsync(out, out_stride * 32, ctx->io_out.ptr, n * 32, n * 32, batch,
+                               hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipStreamSynchronize(st));
+  return PM_OK;
+}
+
+extern "C" int pm_fr_ntt(pm_ctx* ctx, const uint64_t* in, size_t in_len, uint64_t* out,
+                         uint32_t log_n, uint32_t flags) {
+  return pm_fr_ntt_batch(ctx, in, in_len, in_len, out, (size_t)1 << (log_n < 32 ? log_n : 0), log_n,
+                         1, flags);
+}

@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's dependency interface for the hot path.
+
+Names, argument meaning and error behaviour follow dusk-plonk 0.8.2 / dusk-bls12_381 0.8
+(the crates pinned by ref:Cargo.toml:19-20):
+
+* ``EvaluationDomain::new(num_coeffs)`` -> :class:`EvaluationDomain`; ``fft``, ``ifft``,
+  ``coset_fft``, ``coset_ifft`` zero-pad to ``size`` and return a new vector.
+* ``msm_variable_base(points, scalars)`` -> :func:`msm_variable_base`.
+* ``CommitKey { powers_of_g }.commit(poly)`` -> :class:`CommitKey`.
+
+Vectors are ``numpy.uint64`` arrays in the Rust types' memory layout: Fr ``[n, 4]``
+Montgomery limbs, affine G1 ``[n, 12]`` (x | y, (0, 0) = identity), projective ``[18]``.
+Everything here is plumbing: the arithmetic is in ``csrc/`` behind ``include/plonk_mi355x.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import u64p, u32p
+
+
+class Error(Exception):
+    """Non-zero ``pm_status`` from the C ABI (``code``) with the library's message."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"plonk_mi355x error {code}: {msg}")
+        self.code = code
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(u64p)
+
+
+def _fr(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.size % 4:
+        raise ValueError("Fr array must have 4 limbs per element")
+    return a.reshape(-1, 4)
+
+
+class Context:
+    """One GPU, one stream, cached twiddle tables (``pm_ctx``).  Fails loudly without a
+    gfx950 device or without the built HIP library -- there is no CPU path."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.pm_init(device, C.byref(h))
+        if rc != _lib.PM_OK:
+            raise Error(rc, "pm_init failed (no usable gfx950 device?)")
+        self._h = h
+        self.device = device
+
+    def _check(self, rc: int):
+        if rc != _lib.PM_OK:
+            raise Error(rc, self._lib.pm_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pm_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self._lib.pm_sync(self._h))
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.pm_set_option(self._h, key.encode(), int(value)))
+
+    # ---- raw ABI calls -------------------------------------------------------------
+    def fr_ntt(self, a, log_n: int, flags: int = 0, out=None) -> np.ndarray:
+        a = _fr(a)
+        n = 1 << log_n if log_n < 64 else 0
+        if out is None:
+            out = np.empty((n if log_n < 32 else 0, 4), dtype=np.uint64)
+        src = a if a.shape[0] else np.zeros((1, 4), np.uint64)
+        self._check(self._lib.pm_fr_ntt(self._h, _p(src), a.shape[0], _p(out), log_n, flags))
+        return out
+
+    def fr_ntt_batch(self, a, log_n: int, flags: int = 0) -> np.ndarray:
+        """a: [batch, in_len, 4] -> [batch, 2^log_n, 4]."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        batch, in_len = a.shape[0], a.shape[1]
+        n = 1 << log_n
+        out = np.empty((batch, n, 4), dtype=np.uint64)
+        self._check(self._lib.pm_fr_ntt_batch(self._h, _p(a), in_len, in_len, _p(out), n, log_n,
+                                              batch, flags))
+        return out
+
+    def fr_ntt_dev(self, d_in: int, in_len: int, d_out: int, log_n: int, flags: int = 0,
+                   batch: int = 1, in_stride: int | None = None, out_stride: int | None = None,
+                   stream: int = 0):
+        """Device pointers (ints, e.g. ``tensor.data_ptr()``); asynchronous on ``stream``."""
+        n = 1 << log_n
+        self._check(self._lib.pm_fr_ntt_dev(
+            self._h, C.c_void_p(d_in), in_len, in_stride if in_stride is not None else in_len,
+            C.c_void_p(d_out), out_stride if out_stride is not None else n, log_n, batch, flags,
+            C.c_void_p(stream)))
+
+    def field_op(self, op: int, a, b) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.empty_like(a)
+        limbs = 4 if op < 3 else 6
+        self._check(self._lib.pm_test_field_op(self._h, op, _p(a), _p(b), _p(out), a.size // limbs))
+        return out
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def domain_info(log_n: int):
+    """(group_gen, group_gen_inv, size_inv) of the 2^log_n domain.  Host arithmetic only."""
+    lib = _lib.load()
+    g, gi, si = (np.zeros(4, np.uint64) for _ in range(3))
+    rc = lib.pm_domain_info(log_n, _p(g), _p(gi), _p(si))
+    if rc != _lib.PM_OK:
+        raise Error(rc, "log_size_of_group >= TWO_ADICITY (32)")
+    return g, gi, si
+
+
+def ntt_plan(log_n: int):
+    lib = _lib.load()
+    radix = (C.c_uint32 * 4)()
+    npass = C.c_uint32()
+    rc = lib.pm_ntt_plan(log_n, radix, C.byref(npass))
+    if rc != _lib.PM_OK:
+        raise Error(rc, "log_size_of_group >= TWO_ADICITY (32)")
+    return [int(radix[i]) for i in range(npass.value)]
+
+
+class EvaluationDomain:
+    """``dusk_plonk::fft::EvaluationDomain`` (ark-poly ``Radix2EvaluationDomain``)."""
+
+    def __init__(self, num_coeffs: int, ctx: Context | None = None):
+        size = 1
+        while size < num_coeffs:
+            size <<= 1
+        self.size = size
+        self.log_size_of_group = size.bit_length() - 1
+        # InvalidEvalDomainSize in the reference: log2(size) must be < TWO_ADICITY
+        self.group_gen, self.group_gen_inv, self.size_inv = domain_info(self.log_size_of_group)
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def _run(self, a, flags):
+        a = _fr(a)
+        if a.shape[0] > self.size:
+            # the reference's resize() would silently truncate; no prover call site does that
+            raise Error(_lib.PM_ERR_LENGTH, "input longer than the domain")
+        return self.ctx.fr_ntt(a, self.log_size_of_group, flags)
+
+    def fft(self, coeffs):
+        return self._run(coeffs, 0)
+
+    def ifft(self, evals):
+        return self._run(evals, _lib.NTT_INVERSE)
+
+    def coset_fft(self, coeffs):
+        return self._run(coeffs, _lib.NTT_COSET)
+
+    def coset_ifft(self, evals):
+        return self._run(evals, _lib.NTT_INVERSE | _lib.NTT_COSET)
+
+    def elements(self):
+        """All domain elements 1, g, g^2, ... = fft of X (the polynomial with coefficients [0, 1])."""
+        if self.size == 1:
+            return self.fft(_one_mont()[None, :])
+        x = np.zeros((2, 4), np.uint64)
+        x[1] = _one_mont()
+        return self.fft(x)
+
+
+def _one_mont() -> np.ndarray:
+    return np.array([0x00000001FFFFFFFE, 0x5884B7FA00034802, 0x998C4FEFECBC4FF5, 0x1824B159ACC5056F],
+                    dtype=np.uint64)
+
+
+# --------------------------------------------------------------------------- MSM
+class Bases:
+    """Device-resident affine bases (``pm_bases``)."""
+
+    def __init__(self, ctx: Context, points_xy):
+        p = np.ascontiguousarray(points_xy, dtype=np.uint64).reshape(-1, 12)
+        self.ctx = ctx
+        self.n = p.shape[0]
+        h = C.c_void_p()
+        src = p if self.n else np.zeros((1, 12), np.uint64)
+        ctx._check(ctx._lib.pm_g1_bases_upload(ctx._h, _p(src), self.n, C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            self.ctx._lib.pm_g1_bases_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def msm(self, scalars, scalar_form: int = _lib.SCALAR_MONTGOMERY, n: int | None = None) -> np.ndarray:
+        s = _fr(scalars)
+        n = s.shape[0] if n is None else n
+        out = np.zeros(18, np.uint64)
+        src = s if s.shape[0] else np.zeros((1, 4), np.uint64)
+        self.ctx._check(self.ctx._lib.pm_g1_msm(self.ctx._h, self._h, n, _p(src), scalar_form, _p(out)))
+        return out
+
+    def msm_dev(self, d_scalars: int, n: int, offset: int = 0,
+                scalar_form: int = _lib.SCALAR_MONTGOMERY, stream: int = 0) -> np.ndarray:
+        out = np.zeros(18, np.uint64)
+        self.ctx._check(self.ctx._lib.pm_g1_msm_dev(self.ctx._h, self._h, offset, n, C.c_void_p(d_scalars),
+                                                    scalar_form, _p(out), C.c_void_p(stream)))
+        return out
+
+
+def msm_variable_base(points, scalars, ctx: Context | None = None,
+                      scalar_form: int = _lib.SCALAR_MONTGOMERY) -> np.ndarray:
+    """``dusk_bls12_381::multiscalar_mul::msm_variable_base(points, scalars) -> G1Projective``.
+    Uploads the bases for this one call; use :class:`CommitKey` to keep an SRS resident."""
+    ctx = ctx or default_context()
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    s = _fr(scalars)
+    if p.shape[0] != s.shape[0]:
+        raise Error(_lib.PM_ERR_LENGTH, "points and scalars differ in length")
+    b = Bases(ctx, p)
+    try:
+        return b.msm(s, scalar_form)
+    finally:
+        b.free()
+
+
+def g1_fold(parts) -> np.ndarray:
+    lib = _lib.load()
+    parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 18)
+    out = np.zeros(18, np.uint64)
+    rc = lib.pm_g1_fold(_p(parts), parts.shape[0], _p(out))
+    if rc != _lib.PM_OK:
+        raise Error(rc, "pm_g1_fold")
+    return out
+
+
+def g1_to_affine(xyz):
+    """-> (xy[12], is_identity)"""
+    lib = _lib.load()
+    xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(18)
+    out = np.zeros(12, np.uint64)
+    ident = C.c_int()
+    rc = lib.pm_g1_to_affine(_p(xyz), _p(out), C.byref(ident))
+    if rc != _lib.PM_OK:
+        raise Error(rc, "pm_g1_to_affine")
+    return out, bool(ident.value)
+
+
+class CommitKey:
+    """``dusk_plonk::commitment_scheme::kzg10::CommitKey``: holds ``powers_of_g`` on the device;
+    ``commit`` checks the degree (PolynomialDegreeTooLarge) and runs one MSM."""
+
+    def __init__(self, powers_of_g, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self._bases = Bases(self.ctx, powers_of_g)
+
+    def max_degree(self) -> int:
+        return self._bases.n - 1
+
+    def commit(self, coeffs) -> np.ndarray:
+        """-> Commitment as affine G1 [12] ((0, 0) for the zero polynomial)."""
+        c = _fr(coeffs)
+        if c.shape[0] > self._bases.n:
+            raise Error(_lib.PM_ERR_LENGTH, "PolynomialDegreeTooLarge")
+        xyz = self._bases.msm(c, _lib.SCALAR_MONTGOMERY)
+        return g1_to_affine(xyz)[0]
