@@ -1,0 +1,207 @@
+// BLS12-381 G1 group law on the device in XYZZ coordinates (x = X/ZZ, y = Y/ZZZ,
+// ZZ^3 = ZZZ^2), over the carry-free Fp of fields.cuh (14 x 28-bit limbs, R' = 2^392).
+//
+// This is the arithmetic under dusk_bls12_381::multiscalar_mul::msm_variable_base
+// (dusk-bls12_381 0.8, pinned at ref:Cargo.toml:20): bucket += point
+// (mixed addition), bucket + bucket, doubling.  Formulas: EFD madd-2008-s, add-2008-s,
+// dbl-2008-s-1 / mdbl-2008-s-1 for y^2 = x^3 + b (a = 0).
+//
+// Bounds, written (B, V) = limbs < B*2^28, value < V*p.  fe_mul needs Ba*Bb < 17 and
+// Va*Vb < 2520 and returns (1, <2).  A point held in registers or memory obeys the class
+//     X (1+, <10)   Y (1+, <5)   ZZ, ZZZ (1, <2)            ("1+" = limbs < 2^28 + 16)
+// which every routine below both accepts and produces.  The identity is carried as a flag
+// in registers and as ZZ == 0 (all limbs) in memory.
+//
+// Exceptional cases are detected after the fact: P = U2 - U1 = 0 mod p makes ZZ3 = ..*P^2
+// congruent to zero, and a Montgomery product (normalised, < 2p) that is 0 mod p has exactly
+// the limbs of 0 or of p.  The slow path (doubling, or the identity for P + (-P)) is then
+// taken by the few lanes that need it.
+#pragma once
+#include "fields.cuh"
+
+namespace pm {
+
+struct Xyzz {
+  Fp x, y, zz, zzz;
+  bool inf;
+};
+
+PM_DEV bool fp_is_zero_product(const Fp& a) {  // a = fe_mul output: is it 0 mod p?
+  constexpr Limbs<14> M = Consts<FpP>::mod_limbs();
+  u32 z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    z |= a.l[i];
+    e |= a.l[i] ^ M.v[i];
+  }
+  return z == 0 || e == 0;
+}
+// exact test for a lazily reduced value (V < 2520): reduce through a product first
+PM_DEV bool fp_is_zero_lazy(const Fp& a) { return fp_is_zero_product(fe_mul<FpP>(a, fe_one<FpP>())); }
+
+PM_DEV Xyzz xyzz_identity() {
+  Xyzz r;
+  r.x = fe_zero<FpP>();
+  r.y = fe_zero<FpP>();
+  r.zz = fe_zero<FpP>();
+  r.zzz = fe_zero<FpP>();
+  r.inf = true;
+  return r;
+}
+
+// 2 * (x, y) for an affine point (mdbl-2008-s-1); x, y in class
+PM_DEV Xyzz xyzz_double_affine(const Fp& x, const Fp& y) {
+  Xyzz r;
+  Fp U = fe_add<FpP>(y, y);                                 // (2+, <10)
+  Fp V = fe_mul<FpP>(U, U);
+  Fp W = fe_mul<FpP>(U, V);
+  Fp S = fe_mul<FpP>(x, V);
+  Fp XX = fe_mul<FpP>(x, x);
+  Fp M = fe_add<FpP>(fe_add<FpP>(XX, XX), XX);              // (3, <6)
+  Fp MM = fe_mul<FpP>(M, M);
+  r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(MM, fe_add<FpP>(S, S)));   // (1+, <7)
+  Fp D = fe_sub<FpP, 8, 1>(S, r.x);                         // (4, <10)
+  Fp YA = fe_mul<FpP>(M, D);
+  Fp YB = fe_mul<FpP>(W, y);
+  r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));            // (1+, <5)
+  r.zz = V;
+  r.zzz = W;
+  r.inf = false;
+  return r;
+}
+
+// 2 * p (dbl-2008-s-1)
+PM_DEV Xyzz xyzz_double(const Xyzz& p) {
+  if (p.inf) return p;
+  Xyzz r = xyzz_double_affine(p.x, p.y);
+  r.zz = fe_mul<FpP>(r.zz, p.zz);
+  r.zzz = fe_mul<FpP>(r.zzz, p.zzz);
+  return r;
+}
+
+// acc + (x2, y2) with (x2, y2) affine, not the identity; x2 (<=1, <1), y2 (<=3, <3)
+PM_DEV Xyzz xyzz_madd(const Xyzz& acc, const Fp& x2, const Fp& y2) {
+  if (acc.inf) {
+    Xyzz r;
+    r.x = x2;
+    r.y = fe_norm<FpP>(y2);
+    r.zz = fe_one<FpP>();
+    r.zzz = fe_one<FpP>();
+    r.inf = false;
+    return r;
+  }
+  Xyzz r;
+  Fp U2 = fe_mul<FpP>(x2, acc.zz);
+  Fp S2 = fe_mul<FpP>(y2, acc.zzz);
+  Fp P = fe_norm<FpP>(fe_sub<FpP, 11, 1>(U2, acc.x));      // (1+, <13)
+  Fp R = fe_norm<FpP>(fe_sub<FpP, 6, 1>(S2, acc.y));       // (1+, <8)
+  Fp PP = fe_mul<FpP>(P, P);
+  Fp PPP = fe_mul<FpP>(P, PP);
+  Fp Q = fe_mul<FpP>(acc.x, PP);
+  Fp RR = fe_mul<FpP>(R, R);
+  Fp t = fe_sub<FpP, 3, 1>(RR, PPP);                       // (4, <5)
+  r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
+  Fp D = fe_sub<FpP, 11, 1>(Q, r.x);                       // (4, <13)
+  Fp YA = fe_mul<FpP>(R, D);
+  Fp YB = fe_mul<FpP>(acc.y, PPP);
+  r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));           // (1+, <5)
+  r.zz = fe_mul<FpP>(acc.zz, PP);
+  r.zzz = fe_mul<FpP>(acc.zzz, PPP);
+  r.inf = false;
+  if (fp_is_zero_product(r.zz)) {  // same x: acc == +-(x2, y2)
+    if (fp_is_zero_lazy(R))
+      r = xyzz_double_affine(x2, fe_norm<FpP>(y2));
+    else
+      r = xyzz_identity();
+  }
+  return r;
+}
+
+// a + b, both in class (add-2008-s)
+PM_DEV Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
+  if (a.inf) return b;
+  if (b.inf) return a;
+  Xyzz r;
+  Fp U1 = fe_mul<FpP>(a.x, b.zz);
+  Fp U2 = fe_mul<FpP>(b.x, a.zz);
+  Fp S1 = fe_mul<FpP>(a.y, b.zzz);
+  Fp S2 = fe_mul<FpP>(b.y, a.zzz);
+  Fp P = fe_norm<FpP>(fe_sub<FpP, 3, 1>(U2, U1));          // (1+, <5)
+  Fp R = fe_norm<FpP>(fe_sub<FpP, 3, 1>(S2, S1));          // (1+, <5)
+  Fp PP = fe_mul<FpP>(P, P);
+  Fp PPP = fe_mul<FpP>(P, PP);
+  Fp Q = fe_mul<FpP>(U1, PP);
+  Fp RR = fe_mul<FpP>(R, R);
+  Fp t = fe_sub<FpP, 3, 1>(RR, PPP);
+  r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
+  Fp D = fe_sub<FpP, 11, 1>(Q, r.x);
+  Fp YA = fe_mul<FpP>(R, D);
+  Fp YB = fe_mul<FpP>(S1, PPP);
+  r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));           // (1+, <5)
+  r.zz = fe_mul<FpP>(fe_mul<FpP>(a.zz, b.zz), PP);
+  r.zzz = fe_mul<FpP>(fe_mul<FpP>(a.zzz, b.zzz), PPP);
+  r.inf = false;
+  if (fp_is_zero_product(r.zz)) {
+    if (fp_is_zero_lazy(R))
+      r = xyzz_double(a);
+    else
+      r = xyzz_identity();
+  }
+  return r;
+}
+
+// k * p for a small non-negative integer k (left-to-right double-and-add)
+PM_DEV Xyzz xyzz_mul_small(const Xyzz& p, u32 k) {
+  Xyzz r = xyzz_identity();
+  if (k == 0 || p.inf) return r;
+  for (int bit = 31 - __clz(k); bit >= 0; --bit) {
+    r = xyzz_double(r);
+    if ((k >> bit) & 1) r = xyzz_add(r, p);
+  }
+  return r;
+}
+
+// ---- memory format: 4 coordinates x 16 words (14 limbs + 2 pad) = 256 bytes ---------------
+PM_DEV Fp ld_fp_limbs(const u32x4* p) {
+  u32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+  Fp r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+  r.l[12] = d.x; r.l[13] = d.y;
+  return r;
+}
+PM_DEV void st_fp_limbs(u32x4* p, const Fp& v) {
+  p[0] = u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+  p[1] = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+  p[2] = u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
+  p[3] = u32x4{v.l[12], v.l[13], 0u, 0u};
+}
+PM_DEV Xyzz ld_xyzz(const u32x4* base, size_t idx) {
+  const u32x4* p = base + 16 * idx;
+  Xyzz r;
+  r.zz = ld_fp_limbs(p + 8);
+  u32 z = 0;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) z |= r.zz.l[i];
+  r.inf = (z == 0);
+  r.x = ld_fp_limbs(p);
+  r.y = ld_fp_limbs(p + 4);
+  r.zzz = ld_fp_limbs(p + 12);
+  return r;
+}
+PM_DEV void st_xyzz(u32x4* base, size_t idx, const Xyzz& v) {
+  u32x4* p = base + 16 * idx;
+  if (v.inf) {
+    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p[i] = z;
+    return;
+  }
+  st_fp_limbs(p, v.x);
+  st_fp_limbs(p + 4, v.y);
+  st_fp_limbs(p + 8, v.zz);
+  st_fp_limbs(p + 12, v.zzz);
+}
+
+}  // namespace pm

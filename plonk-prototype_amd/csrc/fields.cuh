@@ -241,8 +241,6 @@ PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
 }
 
 // compile-time constant 2^e mod m as an element (canonical limbs)
-template <class P>
-PM_DEV Fe<P> fe_pow2(int e_is_constexpr_at_call_site) = delete;
 template <class P, int E>
 PM_DEV Fe<P> fe_pow2() {
   constexpr Limbs<P::N> c = Consts<P>::pow2_mod(E);

@@ -1,0 +1,514 @@
+// G1 variable-base MSM (KZG commit) for gfx950.
+//
+// Replaces dusk_bls12_381::multiscalar_mul::msm_variable_base / pippenger
+// (dusk-bls12_381 0.8, ref:Cargo.toml:20; ark-ec VariableBaseMSM::multi_scalar_mul) as called
+// by dusk_plonk's CommitKey::commit (ref:Cargo.toml:19).  SURVEY.md CS-4, section 8a a8-a10.
+//
+// Pipeline (all on one stream, no host round trip until the window sums come back):
+//   1 msm_digits      scalar -> canonical integer -> signed c-bit digits; one (key, value)
+//                     pair per (window, point): key = window << (c-1) | (|d| - 1),
+//                     value = point index | sign << 31; zero digits get a trash key
+//   2 radix sort      pairs by key (hipcub DeviceRadixSort over key_bits) -> every bucket's
+//                     points are contiguous; the sum is order independent (exact group law)
+//   3 msm_accumulate  segmented reduction with a FIXED chunk of sorted entries per thread, so
+//                     load balance does not depend on the scalar distribution (all-equal
+//                     scalars, the 0/1-heavy witness vectors of a real prover): runs inside a
+//                     chunk go straight to their bucket, the head/tail runs of each chunk go
+//                     to a partial list that the same kernel shape reduces again (XYZZ inputs)
+//                     until one thread is left
+//   4 msm_bucket_reduce  per window: sum_b (b+1) B_b by chunked running sums + one small
+//                     scalar multiple per chunk, then a tree over the chunk results
+//   5 host            16-ish window sums (3.5 KiB) -> Horner fold with c doublings per window
+//                     and the final inversion on one CPU core (a serial chain of ~300 group
+//                     operations: ~0.2 ms on the host, several ms on a single GPU lane)
+//
+// Differences from the reference algorithm are confined to scheduling: signed digits (half
+// the buckets), a window width chosen for the GPU, sort + segmented sum instead of a serial
+// bucket loop.  The result is the same group element, returned in affine-normalised form.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "context.h"
+#include "ec.cuh"
+#include "host_field.h"
+
+namespace pm {
+
+static constexpr u32 KEY_INVALID = 0xffffffffu;
+
+struct MsmGeom {
+  u32 c;         // window bits
+  u32 nwin;      // windows
+  u32 bbits;     // c - 1: bits of the bucket field
+  u32 nbuckets;  // 1 << bbits per window
+  u32 key_bits;  // bbits + bits(nwin)  (+1 so the trash key sorts last)
+  u32 trash;     // key of zero digits
+};
+
+static MsmGeom make_geom(size_t n, long opt_c) {
+  MsmGeom g;
+  u32 lg = 0;
+  while (((size_t)1 << (lg + 1)) <= std::max<size_t>(n, 1)) ++lg;
+  long c = opt_c ? opt_c : std::min<long>(16, std::max<long>(5, (long)lg - 4));
+  g.c = (u32)c;
+  g.nwin = (256 + g.c - 1) / g.c;
+  g.bbits = g.c - 1;
+  g.nbuckets = 1u << g.bbits;
+  u32 wb = 0;
+  while ((1u << wb) < g.nwin + 1) ++wb;  // room for window == nwin (trash)
+  g.key_bits = g.bbits + wb;
+  g.trash = g.nwin << g.bbits;
+  return g;
+}
+
+// ------------------------------------------------------------------ bases
+// ABI affine (R = 2^384 Montgomery, canonical) -> device form (R' = 2^392, canonical saturated)
+__global__ void bases_convert_kernel(const u32x4* in, u32x4* out, size_t n_coords) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_coords) return;
+  Fp v = fe_load<FpP>(in + 3 * i);
+  fe_store<FpP>(out + 3 * i, fe_abi_to_dev<FpP>(v));
+}
+
+// ------------------------------------------------------------------ 1: digits
+__global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_form, MsmGeom g,
+                                  u32* keys, u32* vals) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = fe_load<FrP>(scalars + 2 * i);
+  // Montgomery (x * 2^256): multiply by 2^5 / 2^261 -> x.   Canonical: multiply by one -> x mod r.
+  Fr f;
+  if (scalar_form == PM_SCALAR_MONTGOMERY) {
+    f = fe_zero<FrP>();
+    f.l[0] = 32u;
+  } else {
+    f = fe_one<FrP>();
+  }
+  u32 w[9];
+  fe_canon_pack<FrP>(w, fe_mul<FrP>(s, f));
+  w[8] = 0;
+  u32 carry = 0;
+  const u32 half = 1u << g.bbits;
+  for (u32 k = 0; k < g.nwin; ++k) {
+    const u32 lo = k * g.c, j = lo >> 5, sh = lo & 31;
+    u64 two = (u64)w[j] | ((u64)(j + 1 < 9 ? w[j + 1] : 0u) << 32);
+    u32 d = (u32)(two >> sh) & ((1u << g.c) - 1u);
+    d += carry;
+    u32 neg = 0;
+    if (d > half) {
+      d = (1u << g.c) - d;
+      neg = 1;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    keys[(size_t)k * n + i] = d ? ((k << g.bbits) | (d - 1)) : g.trash;
+    vals[(size_t)k * n + i] = (u32)i | (neg << 31);
+  }
+}
+
+// ------------------------------------------------------------------ 3: segmented accumulate
+// Level 1: sorted (key, point index) pairs, affine bases.  One thread per chunk of L entries.
+struct AccArgs {
+  const u32* keys;
+  const u32* vals;          // level 1: point index | sign << 31
+  const u32x4* pts_in;      // level >= 2: XYZZ list
+  const u32x4* bases;       // level 1: affine device-form bases (96 B each)
+  size_t base_offset;
+  size_t len;               // entries at this level
+  u32 chunk;                // entries per thread
+  u32 trash;                // level 1: first key that is not a bucket
+  u32 final_level;          // 1: every run goes to its bucket
+  u32x4* buckets;           // XYZZ, indexed by key
+  u32* part_keys;           // 2 per thread
+  u32x4* part_pts;
+};
+
+PM_DEV void flush_run(const AccArgs& a, size_t t, u32 key, const Xyzz& acc, bool head, bool tail) {
+  if (a.final_level || (!head && !tail)) {
+    st_xyzz(a.buckets, key, acc);
+  } else {
+    const size_t slot = 2 * t + (tail ? 1 : 0);  // a single-run chunk counts as a tail
+    a.part_keys[slot] = key;
+    st_xyzz(a.part_pts, slot, acc);
+  }
+}
+
+template <bool LEVEL1>
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const AccArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (a.len + a.chunk - 1) / a.chunk;
+  if (t >= nthreads) return;
+  const size_t lo = t * a.chunk, hi = lo + a.chunk < a.len ? lo + a.chunk : a.len;
+  if (!a.final_level) {
+    a.part_keys[2 * t] = KEY_INVALID;
+    a.part_keys[2 * t + 1] = KEY_INVALID;
+  }
+  u32 cur = KEY_INVALID;
+  bool first_run = true;
+  Xyzz acc = xyzz_identity();
+  for (size_t e = lo; e < hi; ++e) {
+    const u32 k = a.keys[e];
+    if (LEVEL1) {
+      if (k >= a.trash) break;  // sorted: only zero digits from here on
+    } else {
+      if (k == KEY_INVALID) continue;  // hole in the partial list
+    }
+    if (k != cur) {
+      if (cur != KEY_INVALID) {
+        flush_run(a, t, cur, acc, first_run, false);
+        first_run = false;
+      }
+      cur = k;
+      acc = xyzz_identity();
+    }
+    if (LEVEL1) {
+      const u32 v = a.vals[e];
+      const u32x4* bp = a.bases + 6 * (a.base_offset + (size_t)(v & 0x7fffffffu));
+      Fp x = fe_load<FpP>(bp), y = fe_load<FpP>(bp + 3);
+      u32 nz = 0;
+#pragma unroll
+      for (int i = 0; i < 14; ++i) nz |= x.l[i] | y.l[i];
+      if (nz == 0) continue;  // the point at infinity among the bases
+      if (v >> 31) y = fe_sub<FpP, 2, 1>(fe_zero<FpP>(), y);  // -y as 2p - y   (3, <2)
+      acc = xyzz_madd(acc, x, y);
+    } else {
+      acc = xyzz_add(acc, ld_xyzz(a.pts_in, e));
+    }
+  }
+  if (cur != KEY_INVALID) flush_run(a, t, cur, acc, first_run, true);
+}
+
+// ------------------------------------------------------------------ 4: bucket reduce
+// red[w * nt + t] = sum_{b in chunk t} (b + 1) * B[w][b]
+__global__ void __launch_bounds__(64) msm_bucket_chunk_kernel(const u32x4* buckets, u32 nbuckets, u32 lb,
+                                                              u32 total_chunks, u32x4* red) {
+  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_chunks) return;
+  const u32 nt = nbuckets / lb;
+  const u32 w = gid / nt, t = gid % nt;
+  const u32 b0 = t * lb;
+  const u32x4* B = buckets + (size_t)16 * ((size_t)w * nbuckets);
+  Xyzz running = xyzz_identity(), sum = xyzz_identity();
+  for (u32 i = lb; i-- > 0;) {
+    Xyzz b = ld_xyzz(B, b0 + i);
+    running = xyzz_add(running, b);
+    sum = xyzz_add(sum, running);
+  }
+  sum = xyzz_add(sum, xyzz_mul_small(running, b0));
+  st_xyzz(red, gid, sum);
+}
+// out[w] = sum_t red[w * nt + t]   (one 64-thread workgroup per window, tree through LDS)
+__global__ void __launch_bounds__(64) msm_window_sum_kernel(const u32x4* red, u32 nt, u32x4* out) {
+  __shared__ u32x4 sh[64 * 16];
+  const u32 w = blockIdx.x, tid = threadIdx.x;
+  Xyzz acc = xyzz_identity();
+  for (u32 i = tid; i < nt; i += 64) acc = xyzz_add(acc, ld_xyzz(red, (size_t)w * nt + i));
+  st_xyzz(sh, tid, acc);
+  __syncthreads();
+  for (u32 s = 32; s > 0; s >>= 1) {
+    if (tid < s) {
+      acc = xyzz_add(ld_xyzz(sh, tid), ld_xyzz(sh, tid + s));
+    }
+    __syncthreads();
+    if (tid < s) st_xyzz(sh, tid, acc);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (!acc.inf) {  // hand the host values below 2p (they must fit 384 bits)
+      acc.x = fe_mul<FpP>(acc.x, fe_one<FpP>());
+      acc.y = fe_mul<FpP>(acc.y, fe_one<FpP>());
+    }
+    st_xyzz(out, w, acc);
+  }
+}
+
+// ------------------------------------------------------------------ host-side group law
+using host::HFp;
+using host::XYZZ;
+
+// device limbs (14 x 28 bit, value < 2^384, Montgomery R' = 2^392) -> host Montgomery (R = 2^384)
+static HFp limbs_to_host(const u32* l) {
+  HFp v = host::zero<6>();
+  u64 nl[14], carry = 0;
+  for (int i = 0; i < 14; ++i) {  // full carry so the 28-bit fields cannot overlap
+    u64 t = (u64)l[i] + carry;
+    nl[i] = (i == 13) ? t : (t & 0xfffffffull);
+    carry = t >> 28;
+  }
+  for (int i = 0; i < 14; ++i) {
+    const int lo = 28 * i, j = lo / 64, sh = lo % 64;
+    v.l[j] |= nl[i] << sh;
+    if (sh + 28 > 64 && j + 1 < 6) v.l[j + 1] |= nl[i] >> (64 - sh);
+  }
+  HFp c = host::zero<6>();
+  c.l[376 / 64] = (u64)1 << (376 % 64);  // x * 2^392 * 2^376 / 2^384 = x * 2^384
+  return host::mul(v, c, host::FP());
+}
+static XYZZ xyzz_to_host(const u32* p) {  // p: 64 words
+  XYZZ r;
+  bool z = true;
+  for (int i = 0; i < 14; ++i) z = z && p[32 + i] == 0;
+  if (z) return host::xyzz_identity();
+  r.x = limbs_to_host(p);
+  r.y = limbs_to_host(p + 16);
+  r.zz = limbs_to_host(p + 32);
+  r.zzz = limbs_to_host(p + 48);
+  return r;
+}
+static void write_projective(uint64_t out[18], const XYZZ& p) {
+  HFp x, y;
+  memset(out, 0, 18 * 8);
+  if (!host::xyzz_to_affine(p, x, y)) {
+    memcpy(out + 6, host::FP().one, 48);  // (0, 1, 0)
+    return;
+  }
+  memcpy(out, x.l, 48);
+  memcpy(out + 6, y.l, 48);
+  memcpy(out + 12, host::FP().one, 48);
+}
+static XYZZ projective_to_xyzz(const uint64_t* xyz) {  // homogeneous (X/Z, Y/Z)
+  const host::Field<6>& F = host::FP();
+  HFp X, Y, Z;
+  memcpy(X.l, xyz, 48);
+  memcpy(Y.l, xyz + 6, 48);
+  memcpy(Z.l, xyz + 12, 48);
+  if (host::is_zero(Z)) return host::xyzz_identity();
+  XYZZ r;  // x = X/Z = (X Z)/Z^2, y = Y/Z = (Y Z^2)/Z^3
+  HFp z2 = host::mul(Z, Z, F);
+  r.x = host::mul(X, Z, F);
+  r.y = host::mul(Y, z2, F);
+  r.zz = z2;
+  r.zzz = host::mul(z2, Z, F);
+  return r;
+}
+
+// ------------------------------------------------------------------ driver
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars,
+            u32 scalar_form, uint64_t out_xyz[18], hipStream_t st) {
+  if (n == 0) {
+    write_projective(out_xyz, host::xyzz_identity());
+    return PM_OK;
+  }
+  if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
+  const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits);
+  const size_t m = n * g.nwin;  // (key, value) pairs
+  const u32 L1 = 32, LN = 16;
+  // level sizes
+  std::vector<size_t> lens;  // lens[0] = m (level 1 input), lens[i] = partial list length
+  lens.push_back(m);
+  {
+    size_t len = m, chunk = L1;
+    while (true) {
+      size_t nthr = (len + chunk - 1) / chunk;
+      if (nthr <= 1) break;
+      len = 2 * nthr;
+      lens.push_back(len);
+      chunk = LN;
+    }
+  }
+  const size_t total_buckets = (size_t)g.nbuckets * g.nwin;
+  const u32 LB = std::min<u32>(32, g.nbuckets);
+  const u32 chunks_per_win = g.nbuckets / LB;
+  const size_t total_chunks = (size_t)chunks_per_win * g.nwin;
+
+  // workspace layout
+  size_t sort_tmp = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const u32*)nullptr, (u32*)nullptr,
+                                     (const u32*)nullptr, (u32*)nullptr, (int)m, 0, (int)g.key_bits, st);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const size_t o_keys0 = take(m * 4), o_vals0 = take(m * 4), o_keys1 = take(m * 4), o_vals1 = take(m * 4);
+  const size_t o_sort = take(sort_tmp);
+  const size_t o_buckets = take(total_buckets * 256);
+  std::vector<size_t> o_pkeys(lens.size()), o_ppts(lens.size());
+  for (size_t i = 1; i < lens.size(); ++i) {
+    o_pkeys[i] = take(lens[i] * 4);
+    o_ppts[i] = take(lens[i] * 256);
+  }
+  const size_t o_red = take(total_chunks * 256);
+  const size_t o_win = take((size_t)g.nwin * 256);
+  int rc = ensure_buffer(ctx, ctx->msm_ws, off);
+  if (rc) return rc;
+  char* ws = (char*)ctx->msm_ws.ptr;
+  u32 *keys0 = (u32*)(ws + o_keys0), *vals0 = (u32*)(ws + o_vals0);
+  u32 *keys1 = (u32*)(ws + o_keys1), *vals1 = (u32*)(ws + o_vals1);
+  u32x4* buckets = (u32x4*)(ws + o_buckets);
+
+  if (!ctx->msm_host_pinned) {
+    PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, 64 * 256, hipHostMallocDefault));
+    ctx->msm_host_pinned_bytes = 64 * 256;
+  }
+
+  // 1 digits
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (const u32x4*)d_scalars, n, scalar_form, g, keys0, vals0);
+  PM_HIP(ctx, hipGetLastError());
+  // 2 sort
+  PM_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sort_tmp, (const u32*)keys0, keys1,
+                                                 (const u32*)vals0, vals1, (int)m, 0, (int)g.key_bits, st));
+  // 3 accumulate
+  PM_HIP(ctx, hipMemsetAsync(buckets, 0, total_buckets * 256, st));
+  AccArgs a;
+  memset(&a, 0, sizeof a);
+  a.bases = (const u32x4*)bases->d_xy;
+  a.base_offset = offset;
+  a.trash = g.trash;
+  a.buckets = buckets;
+  for (size_t lvl = 0; lvl < lens.size(); ++lvl) {
+    const bool last = (lvl + 1 == lens.size());
+    a.len = lens[lvl];
+    a.chunk = lvl == 0 ? L1 : LN;
+    if (last) a.chunk = (u32)std::max<size_t>(a.chunk, a.len);  // one thread takes what is left
+    a.final_level = last ? 1u : 0u;
+    if (lvl == 0) {
+      a.keys = keys1;
+      a.vals = vals1;
+    } else {
+      a.keys = (const u32*)(ws + o_pkeys[lvl]);
+      a.pts_in = (const u32x4*)(ws + o_ppts[lvl]);
+    }
+    if (!last) {
+      a.part_keys = (u32*)(ws + o_pkeys[lvl + 1]);
+      a.part_pts = (u32x4*)(ws + o_ppts[lvl + 1]);
+    }
+    const size_t nthr = (a.len + a.chunk - 1) / a.chunk;
+    const unsigned blocks = (unsigned)((nthr + 127) / 128);
+    if (lvl == 0)
+      hipLaunchKernelGGL((msm_accumulate_kernel<true>), dim3(blocks), dim3(128), 0, st, a);
+    else
+      hipLaunchKernelGGL((msm_accumulate_kernel<false>), dim3(blocks), dim3(128), 0, st, a);
+    PM_HIP(ctx, hipGetLastError());
+  }
+  // 4 bucket reduce
+  hipLaunchKernelGGL(msm_bucket_chunk_kernel, dim3((unsigned)((total_chunks + 63) / 64)), dim3(64), 0, st,
+                     (const u32x4*)buckets, g.nbuckets, LB, (u32)total_chunks, (u32x4*)(ws + o_red));
+  PM_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(msm_window_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red),
+                     chunks_per_win, (u32x4*)(ws + o_win));
+  PM_HIP(ctx, hipGetLastError());
+  // 5 host fold
+  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)g.nwin * 256, hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipStreamSynchronize(st));
+  const u32* hw = (const u32*)ctx->msm_host_pinned;
+  XYZZ total = host::xyzz_identity();
+  for (u32 w = g.nwin; w-- > 0;) {
+    for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
+    total = host::xyzz_add(total, xyzz_to_host(hw + 64 * w));
+  }
+  write_projective(out_xyz, total);
+  return PM_OK;
+}
+
+}  // namespace pm
+
+// ------------------------------------------------------------------ C ABI
+using namespace pm;
+
+extern "C" int pm_g1_bases_upload(pm_ctx* ctx, const uint64_t* xy, size_t n, pm_bases** out) {
+  if (!ctx || !out || (!xy && n)) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *out = nullptr;
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  pm_bases* b = new pm_bases();
+  b->n = n;
+  b->device = ctx->device;
+  if (n) {
+    void* staging = nullptr;
+    hipError_t e = hipMalloc(&b->d_xy, n * 96);
+    if (e == hipSuccess) e = hipMalloc(&staging, n * 96);
+    if (e != hipSuccess) {
+      if (b->d_xy) (void)hipFree(b->d_xy);
+      delete b;
+      return set_err(ctx, PM_ERR_OOM, "hipMalloc for bases failed");
+    }
+    e = hipMemcpyAsync(staging, xy, n * 96, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(bases_convert_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0,
+                         ctx->stream, (const u32x4*)staging, (u32x4*)b->d_xy, 2 * n);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(staging);
+    if (e != hipSuccess) {
+      (void)hipFree(b->d_xy);
+      delete b;
+      return set_err(ctx, PM_ERR_HIP, std::string("bases upload: ") + hipGetErrorString(e));
+    }
+  }
+  *out = b;
+  return PM_OK;
+}
+
+extern "C" void pm_g1_bases_free(pm_ctx* ctx, pm_bases* bases) {
+  if (!bases) return;
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (bases->d_xy) (void)hipFree(bases->d_xy);
+  }
+  delete bases;
+}
+
+extern "C" size_t pm_g1_bases_len(const pm_bases* bases) { return bases ? bases->n : 0; }
+
+extern "C" int pm_g1_msm_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n,
+                             const void* d_scalars, uint32_t scalar_form, uint64_t out_xyz[18],
+                             void* hip_stream) {
+  if (!ctx || !bases || !out_xyz || (!d_scalars && n)) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (scalar_form > PM_SCALAR_CANONICAL) return set_err(ctx, PM_ERR_BAD_ARG, "scalar_form");
+  if (offset > bases->n || n > bases->n - offset)
+    return set_err(ctx, PM_ERR_LENGTH, "more scalars than uploaded bases");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  return msm_run(ctx, bases, offset, n, d_scalars, scalar_form, out_xyz, st);
+}
+
+extern "C" int pm_g1_msm(pm_ctx* ctx, const pm_bases* bases, size_t n, const uint64_t* scalars,
+                         uint32_t scalar_form, uint64_t out_xyz[18]) {
+  if (!ctx || !bases || !out_xyz || (!scalars && n)) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (scalar_form > PM_SCALAR_CANONICAL) return set_err(ctx, PM_ERR_BAD_ARG, "scalar_form");
+  if (n > bases->n) return set_err(ctx, PM_ERR_LENGTH, "more scalars than uploaded bases");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  if (n) {
+    int rc = ensure_buffer(ctx, ctx->msm_scalars, n * 32);
+    if (rc) return rc;
+    PM_HIP(ctx, hipMemcpyAsync(ctx->msm_scalars.ptr, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return msm_run(ctx, bases, 0, n, ctx->msm_scalars.ptr, scalar_form, out_xyz, ctx->stream);
+}
+
+extern "C" int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]) {
+  if (!out_xyz || (!xyz_parts && k)) return PM_ERR_BAD_ARG;
+  XYZZ total = host::xyzz_identity();
+  for (size_t i = 0; i < k; ++i) total = host::xyzz_add(total, projective_to_xyzz(xyz_parts + 18 * i));
+  write_projective(out_xyz, total);
+  return PM_OK;
+}
+
+extern "C" int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_identity) {
+  if (!xyz || !xy) return PM_ERR_BAD_ARG;
+  XYZZ p = projective_to_xyzz(xyz);
+  HFp x, y;
+  memset(xy, 0, 96);
+  const bool ok = host::xyzz_to_affine(p, x, y);
+  if (ok) {
+    memcpy(xy, x.l, 48);
+    memcpy(xy + 6, y.l, 48);
+  }
+  if (is_identity) *is_identity = ok ? 0 : 1;
+  return PM_OK;
+}
