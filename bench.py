@@ -1,0 +1,211 @@
+"""Headline benchmark: BLS12-381 Fr NTT butterflies/s (+ G1 MSM scalar-muls/s) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run)
+
+A step = one pass of the hot path over one batch of synthetic input resident in HBM:
+a forward and an inverse 2^20-point NTT (BASELINE.json configs[1]).  `value` is whole-job
+butterflies/s over all ranks (weak scaling: every rank transforms its own polynomials, no
+collective on the data path).  The same JSON line carries the MSM leg (configs[2]: 2^20-point
+G1 MSM; with N > 1 the points are sharded over the ranks and the 144-byte partials are
+all-gathered over RCCL and folded), the roofline of the dominant kernel from live hipEvent
+timings, and the CPU baseline (the oracle's C restatement, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--msm-log-n", type=int, default=20)
+    ap.add_argument("--msm-steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-msm", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd.dist import allgather_fold, shard_range
+    from oracle.cpu_oracle import INVERSE, CpuOracle, ints_to_limbs, limbs_to_ints  # cpu_baseline + input synthesis
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    oracle = CpuOracle()
+    ctx = pa.Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ NTT leg (the step)
+    k = args.log_n
+    n = 1 << k
+    host_in = oracle.fr_sample(0x504C4F4E4B + rank, n)          # uniform Fr, Montgomery limbs
+    d_a = torch.from_numpy(host_in.view(np.int64)).to(dev)
+    d_b = torch.empty_like(d_a)
+    d_c = torch.empty_like(d_a)
+
+    def step():
+        ctx.fr_ntt_dev(d_a.data_ptr(), n, d_b.data_ptr(), k, 0, stream=stream)
+        ctx.fr_ntt_dev(d_b.data_ptr(), n, d_c.data_ptr(), k, INVERSE, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    assert torch.equal(d_c, d_a), "iNTT(NTT(a)) != a"            # round trip inside the bench
+    butterflies_per_step = 2 * (n // 2) * k
+    value = world * butterflies_per_step * args.steps / dt
+
+    # roofline of the dominant kernel: algorithmic bytes of one launch / its mean duration
+    passes = pa.ntt_plan(k)
+    kern = {name: (cnt, ms) for name, (cnt, ms) in prof.items() if name.startswith("ntt_pass")}
+    dom = max(kern, key=lambda s: kern[s][1])
+    dom_ms = kern[dom][1] / kern[dom][0]
+    s_dom = passes[0] if dom.endswith("first") or dom.endswith("single") else passes[-1]
+    algo_bytes = 64 * n * s_dom / k                                # 64 N bytes per transform, S/k of it per pass
+    achieved = algo_bytes / (dom_ms * 1e-3)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "ntt_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(f"{dom}_2^{k}")
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                "avg_launch_us": round(dom_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(algo_bytes),
+                "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()},
+                "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
+
+    # ------------------------------------------------------------------ MSM leg
+    msm = None
+    if not args.no_msm:
+        mk = args.msm_log_n
+        mn = 1 << mk
+        lo, hi = shard_range(mn, rank, world)
+        k0, dd = 0x1234567, 0xabcdef123456789abcdef
+        k0_shard = ints_to_limbs([(k0 + lo * dd) % ((1 << 255))], 4)[0]     # P_i = (k0 + i d) G, i in shard
+        pts = oracle.g1_bases_arith(k0_shard, ints_to_limbs([dd], 4)[0], hi - lo, os.cpu_count() or 1)
+        sc = oracle.fr_sample(0x5343414C, mn)[lo:hi]
+        bases = pa.host.Bases(ctx, pts)
+        d_sc = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).to(dev)
+
+        def msm_step():
+            part = bases.msm_dev(d_sc.data_ptr(), hi - lo, stream=stream)
+            return allgather_fold(part, dev if world > 1 else None)
+
+        res = msm_step()
+        barrier()
+        ctx.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.msm_steps):
+            res = msm_step()
+        barrier()
+        mdt = max_over_ranks(time.perf_counter() - t0)
+        mprof = ctx.profile_read()
+        ctx.profile(False)
+        # parity inside the bench: discrete-log identity (bases are known multiples of G)
+        full_sc = oracle.fr_sample(0x5343414C, mn)
+        dl = oracle.expected_dlog(full_sc, 0, ints_to_limbs([k0], 4)[0], ints_to_limbs([dd], 4)[0])
+        ok = bool(np.array_equal(pa.g1_to_affine(res)[0], oracle.g1_mul(oracle.g1_generator(), dl)))
+        acc_ms = mprof["msm_accumulate_l1"][1] / mprof["msm_accumulate_l1"][0]
+        msm = {"metric": "bls12_381_g1_msm_scalar_muls_per_s", "value": mn * args.msm_steps / mdt,
+               "unit": "scalar-muls/s", "points": mn, "ms_per_msm": mdt / args.msm_steps * 1e3,
+               "scaling": "strong" if world > 1 else None, "bit_exact_vs_oracle": ok,
+               "kernels_us": {s: round(v[1] / v[0] * 1e3, 1) for s, v in mprof.items()},
+               "roofline": {"bound": "hbm", "kernel": "msm_accumulate_l1",
+                            "achieved": round(128 * (hi - lo) / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                            "unit": "GB/s", "frac": round(128 * (hi - lo) / (acc_ms * 1e-3) / HBM_PEAK, 5),
+                            "traffic": None}}
+        assert ok, "MSM result differs from the discrete-log identity"
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_oracle = CpuOracle(native=True)       # rebuild with -march=native for this host
+        except Exception:
+            cpu_oracle = oracle
+        cores = os.cpu_count() or 1
+        x = host_in.copy()
+        t0 = time.perf_counter()
+        f1 = cpu_oracle.fr_ntt(x, k, 0, 1)
+        cpu_oracle.fr_ntt(f1, k, INVERSE, 1)
+        t1 = time.perf_counter() - t0
+        reps, tm = 0, 0.0
+        while tm < 6.0 and reps < 50:
+            t0 = time.perf_counter()
+            f = cpu_oracle.fr_ntt(x, k, 0, cores)
+            cpu_oracle.fr_ntt(f, k, INVERSE, cores)
+            tm += time.perf_counter() - t0
+            reps += 1
+        assert np.array_equal(f, d_b.cpu().numpy().view(np.uint64)), "GPU NTT != CPU restatement"
+        cpu = {"value": butterflies_per_step * reps / tm, "unit": "butterflies/s", "cores": cores,
+               "kind": "port",
+               "sample": f"{reps} x (forward + inverse 2^{k} NTT), C restatement of dusk-plonk serial_fft/"
+                         f"parallel_fft (oracle/c, gcc -O3), {cores} threads; 1 thread: "
+                         f"{butterflies_per_step / t1:.3e} butterflies/s",
+               "single_thread_value": butterflies_per_step / t1}
+        if msm is not None:
+            sk = min(args.msm_log_n, 17)
+            sn = 1 << sk
+            t0 = time.perf_counter()
+            cpu_oracle.g1_msm(pts[:sn], sc[:sn], 0, cores)
+            tmsm = time.perf_counter() - t0
+            cpu["msm_value"] = sn / tmsm
+            cpu["msm_unit"] = "scalar-muls/s"
+            cpu["msm_sample"] = f"one 2^{sk}-point Pippenger MSM (c rule of the reference), {cores} threads"
+
+    if rank == 0:
+        out = {"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": value, "unit": "butterflies/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, Fr)",
+               "data": "synthetic",
+               "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "
+                                      f"natural order in/out, bit-exact vs oracle", "log_n": k, "passes": passes,
+                          "parallelism": f"{world} independent polynomial(s), one per GPU"},
+               "roofline": roofline, "cpu_baseline": cpu, "msm": msm}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

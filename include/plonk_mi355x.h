@@ -139,6 +139,10 @@ int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_identity);
 int pm_ntt_plan(uint32_t log_n, uint32_t radix_log2[4], uint32_t* n_passes);
 /* Override tunables: "msm_window_bits", "ntt_tile_log".  Returns PM_ERR_BAD_ARG if unknown. */
 int pm_set_option(pm_ctx* ctx, const char* key, long value);
+/* Opt-in per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline
+ * leg).  pm_profile_read writes lines "<kernel> <launches> <total_ms>\n" into buf. */
+int pm_profile_enable(pm_ctx* ctx, int on);
+int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap);
 /* Elementwise field kernels used by the parity tests: op 0 = Fr mul, 1 = Fr add, 2 = Fr sub,
  * 3 = Fp mul, 4 = Fp add, 5 = Fp sub.  Host pointers, n elements. */
 int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,

@@ -1,6 +1,7 @@
 // Context management, error reporting and the elementwise field-op test hooks.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 
 #include "context.h"
@@ -23,6 +24,41 @@ int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   }
   PM_HIP(ctx, hipMalloc(&b.ptr, bytes));
   b.bytes = bytes;
+  return PM_OK;
+}
+
+static hipEvent_t prof_event(pm_ctx* ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+ProfScope::ProfScope(pm_ctx* c, hipStream_t s, const char* name) : ctx(c), st(s) {
+  if (!ctx->profile) return;
+  hipEvent_t a = prof_event(ctx);
+  stop = prof_event(ctx);
+  (void)hipEventRecord(a, st);
+  ctx->prof_pending.push_back({a, stop, name});
+}
+ProfScope::~ProfScope() {
+  if (stop) (void)hipEventRecord(stop, st);
+}
+int prof_collect(pm_ctx* ctx) {
+  for (auto& p : ctx->prof_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      auto& st = ctx->prof_stats[p.name];
+      st.total_ms += ms;
+      st.count += 1;
+    }
+    ctx->prof_pool.push_back(p.start);
+    ctx->prof_pool.push_back(p.stop);
+  }
+  ctx->prof_pending.clear();
   return PM_OK;
 }
 
@@ -84,6 +120,8 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
                           &ctx->msm_scalars})
     if (b->ptr) hipFree(b->ptr);
   if (ctx->msm_host_pinned) hipHostFree(ctx->msm_host_pinned);
+  prof_collect(ctx);
+  for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -95,6 +133,32 @@ extern "C" int pm_sync(pm_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   PM_HIP(ctx, hipSetDevice(ctx->device));
   PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PM_OK;
+}
+
+extern "C" int pm_profile_enable(pm_ctx* ctx, int on) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  prof_collect(ctx);
+  ctx->profile = on != 0;
+  if (on) ctx->prof_stats.clear();
+  return PM_OK;
+}
+
+extern "C" int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap) {
+  if (!ctx || !buf || cap == 0) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  prof_collect(ctx);
+  std::string out;
+  for (auto& kv : ctx->prof_stats) {
+    char line[256];
+    snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), kv.second.count, kv.second.total_ms);
+    out += line;
+  }
+  if (out.size() + 1 > cap) return set_err(ctx, PM_ERR_BAD_ARG, "profile buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
   return PM_OK;
 }
 

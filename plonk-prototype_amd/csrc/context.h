@@ -41,6 +41,19 @@ struct pm_ctx {
   pm::DeviceBuffer msm_scalars;
   void* msm_host_pinned = nullptr;
   size_t msm_host_pinned_bytes = 0;
+  // opt-in per-kernel timing (hipEvents on the launch stream; read by bench.py)
+  bool profile = false;
+  struct ProfPending {
+    hipEvent_t start, stop;
+    const char* name;
+  };
+  std::vector<ProfPending> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  struct ProfStat {
+    double total_ms = 0;
+    unsigned long long count = 0;
+  };
+  std::map<std::string, ProfStat> prof_stats;
   // tunables
   long opt_msm_window_bits = 0;  // 0 = auto
   long opt_ntt_tile_log = 11;
@@ -56,6 +69,15 @@ struct pm_bases {
 namespace pm {
 
 int set_err(pm_ctx* ctx, int code, const std::string& msg);
+// Scoped kernel timer: records an event pair around the launches issued while it lives.
+struct ProfScope {
+  pm_ctx* ctx;
+  hipStream_t st;
+  hipEvent_t stop = nullptr;
+  ProfScope(pm_ctx* c, hipStream_t s, const char* name);
+  ~ProfScope();
+};
+int prof_collect(pm_ctx* ctx);
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
 
 #define PM_HIP(ctx, call)                                                                   \

@@ -351,12 +351,18 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   }
 
   // 1 digits
+  {
+  ProfScope prof(ctx, st, "msm_digits");
   hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                      (const u32x4*)d_scalars, n, scalar_form, g, keys0, vals0);
+  }
   PM_HIP(ctx, hipGetLastError());
   // 2 sort
-  PM_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sort_tmp, (const u32*)keys0, keys1,
-                                                 (const u32*)vals0, vals1, (int)m, 0, (int)g.key_bits, st));
+  {
+    ProfScope prof(ctx, st, "msm_sort_pairs");
+    PM_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sort_tmp, (const u32*)keys0, keys1,
+                                                   (const u32*)vals0, vals1, (int)m, 0, (int)g.key_bits, st));
+  }
   // 3 accumulate
   PM_HIP(ctx, hipMemsetAsync(buckets, 0, total_buckets * 256, st));
   AccArgs a;
@@ -384,18 +390,24 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
     const size_t nthr = (a.len + a.chunk - 1) / a.chunk;
     const unsigned blocks = (unsigned)((nthr + 127) / 128);
-    if (lvl == 0)
-      hipLaunchKernelGGL((msm_accumulate_kernel<true>), dim3(blocks), dim3(128), 0, st, a);
-    else
-      hipLaunchKernelGGL((msm_accumulate_kernel<false>), dim3(blocks), dim3(128), 0, st, a);
+    {
+      ProfScope prof(ctx, st, lvl == 0 ? "msm_accumulate_l1" : "msm_accumulate_ln");
+      if (lvl == 0)
+        hipLaunchKernelGGL((msm_accumulate_kernel<true>), dim3(blocks), dim3(128), 0, st, a);
+      else
+        hipLaunchKernelGGL((msm_accumulate_kernel<false>), dim3(blocks), dim3(128), 0, st, a);
+    }
     PM_HIP(ctx, hipGetLastError());
   }
   // 4 bucket reduce
+  {
+  ProfScope prof(ctx, st, "msm_bucket_reduce");
   hipLaunchKernelGGL(msm_bucket_chunk_kernel, dim3((unsigned)((total_chunks + 63) / 64)), dim3(64), 0, st,
                      (const u32x4*)buckets, g.nbuckets, LB, (u32)total_chunks, (u32x4*)(ws + o_red));
   PM_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(msm_window_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red),
                      chunks_per_win, (u32x4*)(ws + o_win));
+  }
   PM_HIP(ctx, hipGetLastError());
   // 5 host fold
   PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)g.nwin * 256, hipMemcpyDeviceToHost, st));

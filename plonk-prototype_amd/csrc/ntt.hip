@@ -261,7 +261,11 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
       PM_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     const unsigned blocks = (unsigned)(n >> (S + LT));
-    hipLaunchKernelGGL(fn, dim3(blocks, batch), dim3(threads), lds, st, a, kc);
+    {
+      static const char* kRoleName[4] = {"ntt_pass_single", "ntt_pass_first", "ntt_pass_middle", "ntt_pass_last"};
+      ProfScope prof(ctx, st, kRoleName[role]);
+      hipLaunchKernelGGL(fn, dim3(blocks, batch), dim3(threads), lds, st, a, kc);
+    }
     PM_HIP(ctx, hipGetLastError());
     src = dst;
     log_ns += (unsigned)S;

@@ -75,6 +75,19 @@ class Context:
     def set_option(self, key: str, value: int):
         self._check(self._lib.pm_set_option(self._h, key.encode(), int(value)))
 
+    def profile(self, on: bool):
+        self._check(self._lib.pm_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        """{kernel: (launches, total_ms)} accumulated since profile(True)."""
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self._lib.pm_profile_read(self._h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
     # ---- raw ABI calls -------------------------------------------------------------
     def fr_ntt(self, a, log_n: int, flags: int = 0, out=None) -> np.ndarray:
         a = _fr(a)

@@ -1,0 +1,107 @@
+"""The C-ABI library: loads on a CPU-only box, exports every symbol the header declares,
+fails loudly without a GPU, and its host-side entry points (domain constants, group fold)
+agree with the oracle.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as B
+from oracle.cpu_oracle import ints_to_limbs, limbs_to_ints
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    import plonk_prototype_amd as pa
+    header = open(os.path.join(ROOT, "include", "plonk_mi355x.h")).read()
+    declared = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pm_ctx", "pm_bases", "pm_status"}
+    assert len(declared) >= 18
+    lib = C.CDLL(pa.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    from importlib import import_module
+    sigs = import_module("plonk_prototype_amd._lib").SIGNATURES
+    assert declared == set(sigs), declared ^ set(sigs)
+
+
+def test_no_device_is_a_loud_error():
+    import plonk_prototype_amd as pa
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pa.Error) as e:
+        pa.Context(0)
+    assert e.value.code == -5        # PM_ERR_NO_DEVICE: no CPU fallback exists
+
+
+def test_missing_library_is_a_loud_error(monkeypatch):
+    from importlib import import_module
+    lib = import_module("plonk_prototype_amd._lib")
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libplonk_mi355x.so")
+    with pytest.raises(lib.BackendMissing):
+        lib.load()
+
+
+def test_domain_info_matches_oracle():
+    import plonk_prototype_amd as pa
+    for k in (0, 1, 2, 12, 20, 24, 31):
+        g, gi, si = pa.domain_info(k)
+        d = B.Domain(1 << k)
+        assert limbs_to_ints(g)[0] == B.fr_to_mont(d.group_gen)
+        assert limbs_to_ints(gi)[0] == B.fr_to_mont(d.group_gen_inv)
+        assert limbs_to_ints(si)[0] == B.fr_to_mont(d.size_inv)
+    with pytest.raises(pa.Error) as e:
+        pa.domain_info(32)           # EvaluationDomain::new fails at the two-adicity
+    assert e.value.code == -2
+    with pytest.raises(pa.Error):
+        pa.EvaluationDomain((1 << 32) + 1)
+    d = pa.EvaluationDomain(1000)
+    assert d.size == 1024 and d.log_size_of_group == 10
+
+
+def test_ntt_plan():
+    import plonk_prototype_amd as pa
+    for k in range(3, 32):
+        radices = pa.ntt_plan(k)
+        assert sum(radices) == k and all(3 <= r <= 10 for r in radices)
+    assert pa.ntt_plan(20) == [10, 10] and pa.ntt_plan(24) == [8, 8, 8]
+
+
+def test_fold_and_to_affine_on_host(oracle):
+    import plonk_prototype_amd as pa
+    G = oracle.g1_generator()
+    one = oracle.fp_to_mont(ints_to_limbs([1], 6))[0]
+
+    def proj(xy, z=None):
+        out = np.zeros(18, np.uint64)
+        out[:12] = xy
+        out[12:] = one if z is None else z
+        return out
+
+    ks = [3, 5, 7, 11]
+    pts = [oracle.g1_mul(G, ints_to_limbs([k], 4)[0]) for k in ks]
+    ident = np.zeros(18, np.uint64)
+    ident[6:12] = one
+    parts = np.stack([proj(p) for p in pts] + [ident])
+    folded = pa.g1_fold(parts)
+    aff, is_id = pa.g1_to_affine(folded)
+    assert not is_id and np.array_equal(aff, oracle.g1_mul(G, ints_to_limbs([sum(ks)], 4)[0]))
+    assert np.array_equal(folded[12:], one)                      # normalised Z = 1
+    # P + P (doubling inside the fold), P + (-P) -> identity (0, 1, 0)
+    dbl, _ = pa.g1_to_affine(pa.g1_fold(np.stack([proj(pts[0]), proj(pts[0])])))
+    assert np.array_equal(dbl, oracle.g1_mul(G, ints_to_limbs([6], 4)[0]))
+    neg = pts[0].copy()
+    neg[6:] = oracle.fp_to_mont(ints_to_limbs([B.P_MOD - limbs_to_ints(oracle.fp_from_mont(pts[0][6:].reshape(1, 6)))[0]], 6))[0]
+    z = pa.g1_fold(np.stack([proj(pts[0]), proj(neg)]))
+    assert pa.g1_to_affine(z)[1] and np.array_equal(z[6:12], one) and not z[12:].any()
+    assert pa.g1_to_affine(pa.g1_fold(np.zeros((0, 18), np.uint64)))[1]
+    # non-trivial Z: (X, Y, Z) = (x z, y z, z) is the same point
+    z7 = oracle.fp_to_mont(ints_to_limbs([7], 6))
+    scaled = np.concatenate([oracle.fp_mul(pts[1][:6].reshape(1, 6), z7)[0],
+                             oracle.fp_mul(pts[1][6:].reshape(1, 6), z7)[0], z7[0]])
+    assert np.array_equal(pa.g1_to_affine(scaled)[0], pts[1])
+    assert np.array_equal(oracle.g1_projective_to_affine(scaled), pts[1])

@@ -1,0 +1,80 @@
+"""world_size-2 `gloo` run of the multi-GPU MSM path on CPU: point sharding, the all-gather of
+144-byte partial points and the group-law fold (product host code).  The per-rank partial MSM
+is the GPU kernel in production; here the oracle stands in for it so that the collective and
+the fold are exercised without a device."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import plonk_prototype_amd  # noqa: F401
+    from plonk_prototype_amd.dist import allgather_fold, shard_range
+    from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = CpuOracle()
+        k0 = ints_to_limbs([99], 4)[0]
+        d = ints_to_limbs([0x1000000000001], 4)[0]
+        pts = o.g1_bases_arith(k0, d, n, 1)
+        sc = o.fr_sample(31337, n)
+        lo, hi = shard_range(n, rank, world)
+        part_aff = o.g1_msm(pts[lo:hi], sc[lo:hi])
+        part = np.zeros(18, np.uint64)
+        one = o.fp_to_mont(ints_to_limbs([1], 6))[0]
+        if part_aff.any():
+            part[:12] = part_aff
+            part[12:] = one
+        else:
+            part[6:12] = one
+        total = allgather_fold(part)
+        q.put((rank, total.tolist(), o.g1_msm(pts, sc).tolist(), (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [37, 2])
+def test_sharded_msm_fold_world2(n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ranges = sorted(r[3] for r in res)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n
+    for rank, total, full, _ in res:
+        assert total[:12] == full and total[12:] != [0] * 6, rank   # same point on every rank, Z = 1
+
+
+def test_shard_range_partitions():
+    from plonk_prototype_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 5):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,163 @@
+"""Parity of the HIP MSM (through the C ABI) with the oracle, compared in affine form:
+golden vectors, the reference's edge cases (zero / unit / r-1 scalars, infinity, duplicate
+and opposite bases, the n = 31/32/33 window switch), skewed scalar distributions, both
+scalar forms, every window width, and the discrete-log identity at 2^20."""
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as B
+from oracle.cpu_oracle import SCALAR_CANONICAL, SCALAR_MONTGOMERY, ints_to_limbs, limbs_to_ints
+from conftest import hex_to_fr_mont, points_to_mont
+
+pytestmark = pytest.mark.gpu
+K0 = ints_to_limbs([0x1234567], 4)[0]
+DD = ints_to_limbs([0xabcdef123456789abcdef], 4)[0]
+
+
+def gpu_msm_affine(ctx, pts, sc, form=SCALAR_MONTGOMERY):
+    import plonk_prototype_amd as pa
+    xyz = pa.msm_variable_base(pts, sc, ctx, form)
+    aff, ident = pa.g1_to_affine(xyz)
+    assert ident == (not aff.any())
+    return aff
+
+
+def test_golden_vectors(ctx, oracle, golden):
+    for v in golden["msm"]:
+        pts = points_to_mont(oracle, v["points"])
+        sc = hex_to_fr_mont(oracle, v["scalars"])
+        got = gpu_msm_affine(ctx, pts, sc)
+        if v["result"] is None:
+            assert not got.any()
+        else:
+            x, y = limbs_to_ints(oracle.fp_from_mont(got.reshape(2, 6)))
+            assert (x, y) == (int(v["result"][0], 16), int(v["result"][1], 16)), v["n"]
+
+
+def _edge_inputs(oracle, n, seed):
+    pts = oracle.g1_bases_arith(K0, DD, max(n, 1), 8)[:n]
+    sc = oracle.fr_sample(seed, n)
+    if n > 8:
+        sc[0] = 0
+        sc[1] = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+        sc[2] = oracle.fr_to_mont(ints_to_limbs([B.R_MOD - 1], 4))[0]
+        pts[4] = pts[3]
+        sc[4] = sc[3]                                   # duplicate base and scalar (bucket doubling)
+        y6 = limbs_to_ints(oracle.fp_from_mont(pts[6, 6:].reshape(1, 6)))[0]
+        pts[5, :6] = pts[6, :6]
+        pts[5, 6:] = oracle.fp_to_mont(ints_to_limbs([B.P_MOD - y6], 6))[0]
+        sc[5] = sc[6]                                   # P and -P, equal scalars (bucket cancels)
+        pts[7] = 0                                      # infinity among the bases
+    return pts, sc
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 100, 1000, 4097, 1 << 14, 1 << 16])
+def test_sizes_and_edge_cases(ctx, oracle, n):
+    pts, sc = _edge_inputs(oracle, n, 900 + n)
+    exp = oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 8)
+    assert np.array_equal(gpu_msm_affine(ctx, pts, sc), exp)
+    canon = oracle.fr_from_mont(sc) if n else sc
+    assert np.array_equal(gpu_msm_affine(ctx, pts, canon, SCALAR_CANONICAL), exp)
+
+
+def test_trivial_scalars(ctx, oracle):
+    n = 300
+    pts = oracle.g1_bases_arith(K0, DD, n, 8)
+    assert not gpu_msm_affine(ctx, pts, np.zeros((n, 4), np.uint64)).any()          # all zero -> identity
+    ones = oracle.fr_to_mont(ints_to_limbs([1] * n, 4))
+    assert np.array_equal(gpu_msm_affine(ctx, pts, ones), oracle.g1_msm(pts, ones))  # sum of the bases
+    rm1 = oracle.fr_to_mont(ints_to_limbs([B.R_MOD - 1] * n, 4))
+    assert np.array_equal(gpu_msm_affine(ctx, pts, rm1), oracle.g1_msm(pts, rm1))    # -sum
+    assert not gpu_msm_affine(ctx, np.zeros((n, 12), np.uint64), ones).any()         # all bases infinite
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "zero_one_heavy", "small16", "two_values"])
+def test_skewed_distributions(ctx, oracle, kind):
+    """Load balance must not depend on the digits: a real witness is full of 0, 1 and small values."""
+    n = 1 << 14
+    pts = oracle.g1_bases_arith(K0, DD, n, 8)
+    sc = oracle.fr_sample(8, n)
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+    if kind == "all_equal":
+        sc = np.repeat(oracle.fr_sample(7, 1), n, axis=0)
+    elif kind == "zero_one_heavy":
+        sc[::2] = one
+        sc[1::4] = 0
+    elif kind == "small16":
+        small = [v % 65536 for v in limbs_to_ints(oracle.fr_from_mont(sc))]
+        sc = oracle.fr_to_mont(ints_to_limbs(small, 4))
+    else:
+        sc[: n // 2] = sc[0]
+        sc[n // 2:] = sc[1]
+    assert np.array_equal(gpu_msm_affine(ctx, pts, sc), oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 8))
+
+
+@pytest.mark.parametrize("c", [4, 5, 7, 8, 11, 13, 16, 17, 20])
+def test_every_window_width(ctx, oracle, c):
+    n = 3000
+    pts, sc = _edge_inputs(oracle, n, 55)
+    exp = oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 8)
+    ctx.set_option("msm_window_bits", c)
+    try:
+        assert np.array_equal(gpu_msm_affine(ctx, pts, sc), exp)
+    finally:
+        ctx.set_option("msm_window_bits", 0)
+
+
+def test_commit_key_mirror(ctx, oracle):
+    import plonk_prototype_amd as pa
+    n = 2048
+    pts = oracle.g1_bases_arith(K0, DD, n, 8)
+    ck = pa.CommitKey(pts, ctx)
+    assert ck.max_degree() == n - 1
+    poly = oracle.fr_sample(3, 1500)                                   # commit uses powers_of_g[..len]
+    assert np.array_equal(ck.commit(poly), oracle.g1_msm(pts[:1500], poly))
+    assert np.array_equal(ck.commit(poly), ck.commit(poly))            # deterministic
+    assert not ck.commit(np.zeros((0, 4), np.uint64)).any()            # zero polynomial -> identity
+    with pytest.raises(pa.Error) as e:
+        ck.commit(oracle.fr_sample(3, n + 1))                          # PolynomialDegreeTooLarge
+    assert e.value.code == -6
+    with pytest.raises(pa.Error):
+        pa.msm_variable_base(pts, poly, ctx)                           # length mismatch
+
+
+def test_sharded_msm_fold(ctx, oracle):
+    """The multi-GPU decomposition on one GPU: shard by points, fold the partials."""
+    import plonk_prototype_amd as pa
+    import torch
+    from plonk_prototype_amd.dist import shard_range
+    n = 10007
+    pts = oracle.g1_bases_arith(K0, DD, n, 8)
+    sc = oracle.fr_sample(21, n)
+    bases = pa.host.Bases(ctx, pts)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    parts = []
+    for r in range(3):
+        lo, hi = shard_range(n, r, 3)
+        parts.append(bases.msm_dev(d_sc.data_ptr() + 32 * lo, hi - lo, offset=lo))
+    total, _ = pa.g1_to_affine(pa.g1_fold(np.stack(parts)))
+    assert np.array_equal(total, oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 8))
+
+
+def test_full_size_2_20(ctx, oracle):
+    """BASELINE config 2: 2^20 points.  Bit-exact against the CPU restatement's Pippenger AND the
+    discrete-log identity (bases k_i G => result == (sum s_i k_i) G by one scalar mul)."""
+    import plonk_prototype_amd as pa
+    n = 1 << 20
+    pts = oracle.g1_bases_arith(K0, DD, n, 16)
+    sc = oracle.fr_sample(0x5343414C, n)
+    ck = pa.CommitKey(pts, ctx)
+    got = ck.commit(sc)
+    dl = oracle.expected_dlog(sc, SCALAR_MONTGOMERY, K0, DD)
+    assert np.array_equal(got, oracle.g1_mul(oracle.g1_generator(), dl))
+    assert np.array_equal(got, oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 16))
+    # witness-like distribution: 90 % below 2^16, 5 % zero, 1 % one
+    vals = limbs_to_ints(oracle.fr_from_mont(sc[: 1 << 16]))
+    w = []
+    for i, v in enumerate(vals):
+        m = v % 100
+        w.append(0 if m < 5 else 1 if m == 5 else v % 65536 if m < 96 else v)
+    wl = oracle.fr_to_mont(ints_to_limbs(w, 4))
+    wl = np.tile(wl, (16, 1))
+    dl = oracle.expected_dlog(wl, SCALAR_MONTGOMERY, K0, DD)
+    assert np.array_equal(ck.commit(wl), oracle.g1_mul(oracle.g1_generator(), dl))

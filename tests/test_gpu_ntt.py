@@ -1,0 +1,137 @@
+"""Parity of the HIP NTT (through the C ABI) with the oracle: bit-exact, every transform kind,
+every pass plan, the reference's edge cases, and size-independent properties at full size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as B
+from oracle.cpu_oracle import COSET, INVERSE, ints_to_limbs, limbs_to_ints
+from conftest import hex_to_fr_mont
+
+pytestmark = pytest.mark.gpu
+ALL_FLAGS = [0, INVERSE, COSET, INVERSE | COSET]
+NAMES = {0: "fft", INVERSE: "ifft", COSET: "coset_fft", INVERSE | COSET: "coset_ifft"}
+
+
+def test_golden_vectors(ctx, oracle, golden):
+    for v in golden["ntt"]:
+        a = hex_to_fr_mont(oracle, v["input"])
+        for flags, name in NAMES.items():
+            got = limbs_to_ints(oracle.fr_from_mont(ctx.fr_ntt(a, v["log_n"], flags)))
+            assert got == [int(h, 16) for h in v[name]], (v["log_n"], name)
+
+
+@pytest.mark.parametrize("k", list(range(0, 15)) + [16, 17, 18, 20])
+def test_every_plan_against_oracle(ctx, oracle, k):
+    n = 1 << k
+    a = oracle.fr_sample(0x504C4F4E4B + k, n)
+    for flags in ALL_FLAGS:
+        assert np.array_equal(ctx.fr_ntt(a, k, flags), oracle.fr_ntt(a, k, flags, 8)), (k, flags)
+    # ragged input: zero padding is part of the transform (the reference's resize)
+    for in_len in sorted({0, 1, n // 4 + 1, n - 1} & set(range(n + 1))):
+        for flags in (0, COSET):
+            assert np.array_equal(ctx.fr_ntt(a[:in_len], k, flags), oracle.fr_ntt(a[:in_len], k, flags, 8))
+
+
+@pytest.mark.parametrize("k", [12, 16, 20])
+def test_tile_option_12(ctx, oracle, k):
+    a = oracle.fr_sample(12 + k, 1 << k)
+    ctx.set_option("ntt_tile_log", 12)
+    try:
+        for flags in ALL_FLAGS:
+            assert np.array_equal(ctx.fr_ntt(a, k, flags), oracle.fr_ntt(a, k, flags, 8))
+    finally:
+        ctx.set_option("ntt_tile_log", 11)
+
+
+@pytest.mark.parametrize("k", [2, 7, 10, 13, 20])
+def test_in_place(ctx, oracle, k):
+    a = oracle.fr_sample(3 + k, 1 << k)
+    for flags in ALL_FLAGS:
+        buf = a.copy()
+        out = ctx.fr_ntt(buf, k, flags, out=buf)     # in == out: the *_in_place forms
+        assert out is buf and np.array_equal(buf, oracle.fr_ntt(a, k, flags, 8))
+
+
+@pytest.mark.parametrize("k,batch,in_len", [(1, 3, 2), (5, 4, 20), (10, 6, 1024), (12, 5, 1000), (16, 4, 1 << 14)])
+def test_batch(ctx, oracle, k, batch, in_len):
+    a = oracle.fr_sample(1000 + k, batch * in_len).reshape(batch, in_len, 4)
+    for flags in ALL_FLAGS:
+        got = ctx.fr_ntt_batch(a, k, flags)
+        for b in range(batch):
+            assert np.array_equal(got[b], oracle.fr_ntt(a[b], k, flags, 8)), (k, b, flags)
+
+
+def test_errors(ctx):
+    import plonk_prototype_amd as pa
+    x = np.zeros((8, 4), np.uint64)
+    with pytest.raises(pa.Error) as e:
+        ctx.fr_ntt(x, 32, 0)
+    assert e.value.code == -2                    # log_n >= TWO_ADICITY
+    with pytest.raises(pa.Error) as e:
+        ctx.fr_ntt(x, 2, 0)
+    assert e.value.code == -6                    # input longer than the domain
+    with pytest.raises(pa.Error):
+        ctx._check(ctx._lib.pm_fr_ntt(ctx._h, x.ctypes.data_as(C.POINTER(C.c_uint64)), 8,
+                                       x.ctypes.data_as(C.POINTER(C.c_uint64)), 3, 64))   # unknown flag
+
+
+def test_evaluation_domain_mirror(ctx, oracle):
+    import plonk_prototype_amd as pa
+    d = pa.EvaluationDomain(3000, ctx)
+    assert d.size == 4096 and d.log_size_of_group == 12
+    a = oracle.fr_sample(9, 3000)
+    assert np.array_equal(d.fft(a), oracle.fr_ntt(a, 12, 0))
+    assert np.array_equal(d.ifft(d.fft(a))[:3000], a) and not d.ifft(d.fft(a))[3000:].any()
+    assert np.array_equal(d.coset_ifft(d.coset_fft(a))[:3000], a)
+    # elements() == successive powers of group_gen (upstream's `elements_contents` test)
+    els = limbs_to_ints(oracle.fr_from_mont(d.elements()))
+    assert els == list(B.Domain(4096).elements())
+    assert limbs_to_ints(d.group_gen)[0] == B.fr_to_mont(B.Domain(4096).group_gen)
+
+
+def test_device_resident_api(ctx, oracle):
+    import torch
+    k, n = 14, 1 << 14
+    a = oracle.fr_sample(4, n)
+    t_in = torch.from_numpy(a.view(np.int64)).cuda()
+    t_out = torch.empty_like(t_in)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.fr_ntt_dev(t_in.data_ptr(), n, t_out.data_ptr(), k, 0, stream=st)
+    ctx.fr_ntt_dev(t_out.data_ptr(), n, t_out.data_ptr(), k, INVERSE, stream=st)   # in place
+    torch.cuda.synchronize()
+    assert np.array_equal(t_out.cpu().numpy().view(np.uint64), a)
+
+
+@pytest.mark.parametrize("k", [22, 24])
+def test_full_size_properties(ctx, oracle, k):
+    """BASELINE sizes (2^20 is compared to the oracle above; 4n = 2^22 and 2^24 here):
+    round trips, delta -> ones, linearity and Horner spot checks."""
+    n = 1 << k
+    a = oracle.fr_sample(0x504C4F4E4B, n)
+    f = ctx.fr_ntt(a, k, 0)
+    assert np.array_equal(ctx.fr_ntt(f, k, INVERSE), a)
+    cf = ctx.fr_ntt(a[: n // 4], k, COSET)                         # the prover's 4n coset shape
+    back = ctx.fr_ntt(cf, k, INVERSE | COSET)
+    assert np.array_equal(back[: n // 4], a[: n // 4]) and not back[n // 4:].any()
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))
+    ones = ctx.fr_ntt(one, k, 0)
+    assert np.array_equal(ones, np.broadcast_to(one, (n, 4)))
+    # Horner: NTT(a)[j] == a(w^j) on a short polynomial (cheap on the CPU), coset: a(7 w^j)
+    short = a[:257]
+    sv = limbs_to_ints(oracle.fr_from_mont(short))
+    fs = ctx.fr_ntt(short, k, 0)
+    cs = ctx.fr_ntt(short, k, COSET)
+    w = B.Domain(n).group_gen
+    for j in (0, 1, 12345, n // 2 + 3, n - 1):
+        wj = pow(w, j, B.R_MOD)
+        assert limbs_to_ints(oracle.fr_from_mont(fs[j:j + 1]))[0] == B.horner(sv, wj)
+        assert limbs_to_ints(oracle.fr_from_mont(cs[j:j + 1]))[0] == B.horner(sv, 7 * wj % B.R_MOD)
+    # linearity on a sample of outputs: NTT(a + b) == NTT(a) + NTT(b)
+    b = oracle.fr_sample(77, n)
+    idx = np.array([0, 1, 2, 4097, n // 3, n - 2, n - 1])
+    ab = ctx.field_op(1, a, b)
+    lhs = ctx.fr_ntt(ab, k, 0)[idx]
+    rhs = ctx.field_op(1, np.ascontiguousarray(f[idx]), np.ascontiguousarray(ctx.fr_ntt(b, k, 0)[idx]))
+    assert np.array_equal(lhs, rhs)
