@@ -40,7 +40,8 @@ def main():
     import torch.distributed as dist
     import plonk_prototype_amd as pa
     from plonk_prototype_amd.dist import allgather_fold, shard_range
-    from oracle.cpu_oracle import INVERSE, CpuOracle, ints_to_limbs, limbs_to_ints  # cpu_baseline + input synthesis
+    from oracle.cpu_oracle import INVERSE, CpuOracle, ints_to_limbs  # cpu_baseline + input synthesis + checks
+    from oracle.bigint_oracle import R_MOD
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,7 +121,7 @@ def main():
         mn = 1 << mk
         lo, hi = shard_range(mn, rank, world)
         k0, dd = 0x1234567, 0xabcdef123456789abcdef
-        k0_shard = ints_to_limbs([(k0 + lo * dd) % ((1 << 255))], 4)[0]     # P_i = (k0 + i d) G, i in shard
+        k0_shard = ints_to_limbs([(k0 + lo * dd) % R_MOD], 4)[0]     # P_i = (k0 + i d) G, i in shard
         pts = oracle.g1_bases_arith(k0_shard, ints_to_limbs([dd], 4)[0], hi - lo, os.cpu_count() or 1)
         sc = oracle.fr_sample(0x5343414C, mn)[lo:hi]
         bases = pa.host.Bases(ctx, pts)
