@@ -54,6 +54,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
+        ctx.sync()                       # the library's own stream
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -68,6 +69,8 @@ def main():
     oracle = CpuOracle()
     ctx = pa.Context(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
+    # host threads we may use: the box's CPU share, not every core the kernel lists
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
 
     # ------------------------------------------------------------------ NTT leg (the step)
     k = args.log_n
@@ -122,7 +125,7 @@ def main():
         lo, hi = shard_range(mn, rank, world)
         k0, dd = 0x1234567, 0xabcdef123456789abcdef
         k0_shard = ints_to_limbs([(k0 + lo * dd) % R_MOD], 4)[0]     # P_i = (k0 + i d) G, i in shard
-        pts = oracle.g1_bases_arith(k0_shard, ints_to_limbs([dd], 4)[0], hi - lo, os.cpu_count() or 1)
+        pts = oracle.g1_bases_arith(k0_shard, ints_to_limbs([dd], 4)[0], hi - lo, cores)
         sc = oracle.fr_sample(0x5343414C, mn)[lo:hi]
         bases = pa.host.Bases(ctx, pts)
         d_sc = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).to(dev)
@@ -163,7 +166,6 @@ def main():
             cpu_oracle = CpuOracle(native=True)       # rebuild with -march=native for this host
         except Exception:
             cpu_oracle = oracle
-        cores = os.cpu_count() or 1
         x = host_in.copy()
         t0 = time.perf_counter()
         f1 = cpu_oracle.fr_ntt(x, k, 0, 1)

@@ -59,6 +59,22 @@ class BackendMissing(RuntimeError):
     """The HIP extension is not built / not loadable.  There is no CPU fallback."""
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so with
+    the same SONAME (libamdhip64.so.7) as /opt/rocm's.  Whichever loads first serves both, but
+    if the system copy wins, torch later loads its bundled copy *as well* (it asks for it by
+    file name) and that second runtime finds no GPU.  So when torch is installed, load its
+    copy first; our library's DT_NEEDED then resolves to it and torch tensors, streams and
+    our kernels share one runtime.  Without torch the library uses /opt/rocm via its RUNPATH."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """dlopen the in-tree HIP library and bind every symbol.  Fails loudly when absent."""
     global _lib
@@ -68,6 +84,7 @@ def load() -> C.CDLL:
         raise BackendMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C plonk-prototype_amd/csrc`).  This package has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared export
