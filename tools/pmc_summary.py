@@ -1,0 +1,26 @@
+"""Summarise rocprofv3 --pmc csv output: per kernel, mean counter value per dispatch.
+usage: python tools/pmc_summary.py gpurun_out/r01 profiles/r01_pmc_summary.json"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root, out = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Kernel_Name") or row.get("Kernel Name")
+            acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+summary = {}
+for kname, ctrs in acc.items():
+    if not kname.startswith(("void pm::", "pm::")):
+        continue
+    short = kname.split("(")[0].replace("void ", "")
+    summary[short] = {c: {"mean": sum(v) / len(v), "dispatches": len(v)} for c, v in ctrs.items()}
+    s = summary[short]
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+        # gfx950: FETCH_SIZE (KiB) counts 128-B requests at 64 B for wide streaming reads -> x2 (MI355X_MICROARCH.md, HBM)
+        s["hbm_bytes_per_launch_corrected"] = (2 * s["FETCH_SIZE"]["mean"] + s["WRITE_SIZE"]["mean"]) * 1024
+        s["hbm_bytes_per_launch_raw"] = (s["FETCH_SIZE"]["mean"] + s["WRITE_SIZE"]["mean"]) * 1024
+json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
+for k, v in sorted(summary.items()):
+    print(k, {c: (round(x["mean"]) if isinstance(x, dict) else round(x)) for c, x in v.items()})
