@@ -170,6 +170,16 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_msm_window_bits = value;
     return PM_OK;
   }
+  if (!strcmp(key, "msm_chunk")) {
+    if (value < 0 || value > 4096) return set_err(ctx, PM_ERR_BAD_ARG, "msm_chunk out of range");
+    ctx->opt_msm_chunk = value;
+    return PM_OK;
+  }
+  if (!strcmp(key, "msm_lb")) {
+    if (value < 0 || value > 1024 || (value & (value - 1))) return set_err(ctx, PM_ERR_BAD_ARG, "msm_lb must be a power of two");
+    ctx->opt_msm_lb = value;
+    return PM_OK;
+  }
   if (!strcmp(key, "ntt_tile_log")) {
     if (value != 11 && value != 12) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_tile_log must be 11 or 12");
     ctx->opt_ntt_tile_log = value;

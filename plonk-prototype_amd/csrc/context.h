@@ -57,6 +57,8 @@ struct pm_ctx {
   // tunables
   long opt_msm_window_bits = 0;  // 0 = auto
   long opt_ntt_tile_log = 11;
+  long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
+  long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
   int num_cus = 256;
 };
 

@@ -53,12 +53,12 @@ PM_DEV Xyzz xyzz_identity() {
 PM_DEV Xyzz xyzz_double_affine(const Fp& x, const Fp& y) {
   Xyzz r;
   Fp U = fe_add<FpP>(y, y);                                 // (2+, <10)
-  Fp V = fe_mul<FpP>(U, U);
+  Fp V = fe_sqr<FpP>(U);
   Fp W = fe_mul<FpP>(U, V);
   Fp S = fe_mul<FpP>(x, V);
-  Fp XX = fe_mul<FpP>(x, x);
+  Fp XX = fe_sqr<FpP>(x);
   Fp M = fe_add<FpP>(fe_add<FpP>(XX, XX), XX);              // (3, <6)
-  Fp MM = fe_mul<FpP>(M, M);
+  Fp MM = fe_sqr<FpP>(M);
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(MM, fe_add<FpP>(S, S)));   // (1+, <7)
   Fp D = fe_sub<FpP, 8, 1>(S, r.x);                         // (4, <10)
   Fp YA = fe_mul<FpP>(M, D);
@@ -95,10 +95,10 @@ PM_DEV Xyzz xyzz_madd(const Xyzz& acc, const Fp& x2, const Fp& y2) {
   Fp S2 = fe_mul<FpP>(y2, acc.zzz);
   Fp P = fe_norm<FpP>(fe_sub<FpP, 11, 1>(U2, acc.x));      // (1+, <13)
   Fp R = fe_norm<FpP>(fe_sub<FpP, 6, 1>(S2, acc.y));       // (1+, <8)
-  Fp PP = fe_mul<FpP>(P, P);
+  Fp PP = fe_sqr<FpP>(P);
   Fp PPP = fe_mul<FpP>(P, PP);
   Fp Q = fe_mul<FpP>(acc.x, PP);
-  Fp RR = fe_mul<FpP>(R, R);
+  Fp RR = fe_sqr<FpP>(R);
   Fp t = fe_sub<FpP, 3, 1>(RR, PPP);                       // (4, <5)
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
   Fp D = fe_sub<FpP, 11, 1>(Q, r.x);                       // (4, <13)
@@ -128,10 +128,10 @@ PM_DEV Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
   Fp S2 = fe_mul<FpP>(b.y, a.zzz);
   Fp P = fe_norm<FpP>(fe_sub<FpP, 3, 1>(U2, U1));          // (1+, <5)
   Fp R = fe_norm<FpP>(fe_sub<FpP, 3, 1>(S2, S1));          // (1+, <5)
-  Fp PP = fe_mul<FpP>(P, P);
+  Fp PP = fe_sqr<FpP>(P);
   Fp PPP = fe_mul<FpP>(P, PP);
   Fp Q = fe_mul<FpP>(U1, PP);
-  Fp RR = fe_mul<FpP>(R, R);
+  Fp RR = fe_sqr<FpP>(R);
   Fp t = fe_sub<FpP, 3, 1>(RR, PPP);
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
   Fp D = fe_sub<FpP, 11, 1>(Q, r.x);

@@ -235,9 +235,49 @@ PM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   t.l[N - 1] = (u32)acc;
   return t;
 }
+// a^2 with the cross terms taken once against a pre-doubled copy: N(N+1)/2 products instead of
+// N^2 for the a*a part (the reduction part is unchanged).  Same bounds as fe_mul(a, a).
 template <class P>
 PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
-  return fe_mul<P>(a, a);
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q[N], d[N];
+  Fe<P> t;
+#pragma unroll
+  for (int i = 0; i < N; ++i) d[i] = a.l[i] << 1;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int j = k - i;
+      if (j < 0 || j >= N || i > j) continue;
+      if (i == j)
+        acc += (u64)a.l[i] * a.l[i];
+      else
+        acc += (u64)a.l[i] * d[j];
+    }
+    if (k < N) {
+#pragma unroll
+      for (int i = 0; i < k; ++i) acc += (u64)q[i] * M.v[k - i];
+      if (M.v[0] == 1u) {
+        q[k] = (0u - (u32)acc) & MASK;
+        acc += q[k];
+      } else {
+        q[k] = ((u32)acc * NINV) & MASK;
+        acc += (u64)q[k] * M.v[0];
+      }
+    } else {
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i) acc += (u64)q[i] * M.v[k - i];
+      t.l[k - N] = (u32)acc & MASK;
+    }
+    acc >>= W;
+  }
+  t.l[N - 1] = (u32)acc;
+  return t;
 }
 
 // compile-time constant 2^e mod m as an element (canonical limbs)

@@ -112,7 +112,6 @@ __global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_for
 }
 
 // ------------------------------------------------------------------ 3: segmented accumulate
-// Level 1: sorted (key, point index) pairs, affine bases.  One thread per chunk of L entries.
 struct AccArgs {
   const u32* keys;
   const u32* vals;          // level 1: point index | sign << 31
@@ -121,52 +120,87 @@ struct AccArgs {
   size_t base_offset;
   size_t len;               // entries at this level
   u32 chunk;                // entries per thread
+  u32 offset;               // level >= 2: thread t covers [t*chunk - offset, (t+1)*chunk - offset)
   u32 trash;                // level 1: first key that is not a bucket
   u32 final_level;          // 1: every run goes to its bucket
   u32x4* buckets;           // XYZZ, indexed by key
-  u32* part_keys;           // 2 per thread
+  u32* part_keys;           // 2 per thread: [2t] head run, [2t+1] tail run
   u32x4* part_pts;
 };
 
-PM_DEV void flush_run(const AccArgs& a, size_t t, u32 key, const Xyzz& acc, bool head, bool tail) {
-  if (a.final_level || (!head && !tail)) {
-    st_xyzz(a.buckets, key, acc);
-  } else {
-    const size_t slot = 2 * t + (tail ? 1 : 0);  // a single-run chunk counts as a tail
-    a.part_keys[slot] = key;
-    st_xyzz(a.part_pts, slot, acc);
+PM_DEV Xyzz xyzz_shfl_up1(const Xyzz& v) {
+  Xyzz r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    r.x.l[i] = __shfl_up(v.x.l[i], 1);
+    r.y.l[i] = __shfl_up(v.y.l[i], 1);
+    r.zz.l[i] = __shfl_up(v.zz.l[i], 1);
+    r.zzz.l[i] = __shfl_up(v.zzz.l[i], 1);
   }
+  r.inf = __shfl_up((int)v.inf, 1) != 0;
+  return r;
+}
+PM_DEV Xyzz xyzz_shfl_down(const Xyzz& v, int d) {
+  Xyzz r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    r.x.l[i] = __shfl_down(v.x.l[i], d);
+    r.y.l[i] = __shfl_down(v.y.l[i], d);
+    r.zz.l[i] = __shfl_down(v.zz.l[i], d);
+    r.zzz.l[i] = __shfl_down(v.zzz.l[i], d);
+  }
+  r.inf = __shfl_down((int)v.inf, d) != 0;
+  return r;
 }
 
-template <bool LEVEL1>
-__global__ void __launch_bounds__(128) msm_accumulate_kernel(const AccArgs a) {
+// Level 1: sorted (key, point index) pairs, affine bases, one thread per chunk of `chunk`
+// entries.  A run is classified exactly by looking one key past either end of the chunk:
+//   neither continues    -> complete, stored to its bucket
+//   continues both ways  -> pass-through partial (slot 2t+1)
+//   tail that continues after / head that continues from before: the usual case for uniform
+//   digits is a run split over exactly two neighbouring chunks, i.e. neighbouring LANES, so
+//   lane i hands its open tail to lane i+1 through the register file (one shuffle of the
+//   point) and lane i+1 completes the run with one addition.  Only runs that cross a wave
+//   boundary or span three or more chunks reach the partial list.
+__global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (a.len + a.chunk - 1) / a.chunk;
-  if (t >= nthreads) return;
+  const bool active = t < nthreads;
+  const u32 lane = threadIdx.x & 63u;
   const size_t lo = t * a.chunk, hi = lo + a.chunk < a.len ? lo + a.chunk : a.len;
-  if (!a.final_level) {
-    a.part_keys[2 * t] = KEY_INVALID;
-    a.part_keys[2 * t + 1] = KEY_INVALID;
+  u32 prev_key = KEY_INVALID, next_key = KEY_INVALID;
+  if (active) {
+    if (!a.final_level) {
+      a.part_keys[2 * t] = KEY_INVALID;
+      a.part_keys[2 * t + 1] = KEY_INVALID;
+    }
+    if (lo > 0) prev_key = a.keys[lo - 1];
+    if (hi < a.len) next_key = a.keys[hi];
+    if (next_key >= a.trash) next_key = KEY_INVALID;
   }
-  u32 cur = KEY_INVALID;
-  bool first_run = true;
+  u32 cur = KEY_INVALID, head_key = KEY_INVALID;
+  bool first_run = true, have_head = false, have_tail = false;
   Xyzz acc = xyzz_identity();
-  for (size_t e = lo; e < hi; ++e) {
-    const u32 k = a.keys[e];
-    if (LEVEL1) {
+  if (active) {
+    for (size_t e = lo; e < hi; ++e) {
+      const u32 k = a.keys[e];
       if (k >= a.trash) break;  // sorted: only zero digits from here on
-    } else {
-      if (k == KEY_INVALID) continue;  // hole in the partial list
-    }
-    if (k != cur) {
-      if (cur != KEY_INVALID) {
-        flush_run(a, t, cur, acc, first_run, false);
-        first_run = false;
+      if (k != cur) {
+        if (cur != KEY_INVALID) {  // a run that ends inside the chunk
+          const bool cfb = first_run && cur == prev_key;
+          if (a.final_level || !cfb) {
+            st_xyzz(a.buckets, cur, acc);
+          } else {  // head continuing from the previous chunk: park it in its partial slot
+            a.part_keys[2 * t] = cur;
+            st_xyzz(a.part_pts, 2 * t, acc);
+            have_head = true;
+            head_key = cur;
+          }
+          first_run = false;
+        }
+        cur = k;
+        acc = xyzz_identity();
       }
-      cur = k;
-      acc = xyzz_identity();
-    }
-    if (LEVEL1) {
       const u32 v = a.vals[e];
       const u32x4* bp = a.bases + 6 * (a.base_offset + (size_t)(v & 0x7fffffffu));
       Fp x = fe_load<FpP>(bp), y = fe_load<FpP>(bp + 3);
@@ -176,11 +210,82 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const AccArgs a) {
       if (nz == 0) continue;  // the point at infinity among the bases
       if (v >> 31) y = fe_sub<FpP, 2, 1>(fe_zero<FpP>(), y);  // -y as 2p - y   (3, <2)
       acc = xyzz_madd(acc, x, y);
-    } else {
-      acc = xyzz_add(acc, ld_xyzz(a.pts_in, e));
+    }
+    if (cur != KEY_INVALID) {  // the last run: it ends at the chunk end
+      const bool cfb = first_run && cur == prev_key;
+      const bool ca = cur == next_key;
+      if (a.final_level || (!cfb && !ca)) {
+        st_xyzz(a.buckets, cur, acc);
+      } else if (cfb && !ca) {
+        a.part_keys[2 * t] = cur;
+        st_xyzz(a.part_pts, 2 * t, acc);
+        have_head = true;
+        head_key = cur;
+      } else if (!cfb && ca) {
+        have_tail = true;  // stays in registers for the neighbour exchange
+      } else {
+        a.part_keys[2 * t + 1] = cur;
+        st_xyzz(a.part_pts, 2 * t + 1, acc);
+      }
     }
   }
-  if (cur != KEY_INVALID) flush_run(a, t, cur, acc, first_run, true);
+  // ---- neighbour exchange (all 64 lanes take part)
+  const bool up_has_tail = (__shfl_up((int)have_tail, 1) != 0) && lane != 0;
+  const bool down_has_head = (__shfl_down((int)have_head, 1) != 0) && lane != 63;
+  const Xyzz from_up = xyzz_shfl_up1(acc);
+  if (have_tail && !down_has_head) {  // nobody takes the tail: it goes to the partial list
+    a.part_keys[2 * t + 1] = cur;
+    st_xyzz(a.part_pts, 2 * t + 1, acc);
+  }
+  // (acc is dead from here on: the merge below needs the registers)
+  if (have_head && up_has_tail) {  // complete the run split between lane-1 and this lane
+    Xyzz h = ld_xyzz(a.part_pts, 2 * t);
+    st_xyzz(a.buckets, head_key, xyzz_add(from_up, h));
+    a.part_keys[2 * t] = KEY_INVALID;
+  }
+}
+
+// Level >= 2: a list of (key, XYZZ) partials in key order, with holes (KEY_INVALID).
+__global__ void __launch_bounds__(128) msm_accumulate_ln_kernel(const AccArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (a.len + a.offset + a.chunk - 1) / a.chunk;
+  if (t >= nthreads) return;
+  const size_t lo = t * a.chunk > a.offset ? t * a.chunk - a.offset : 0;
+  size_t hi = (t + 1) * (size_t)a.chunk - a.offset;
+  if (hi > a.len) hi = a.len;
+  if (!a.final_level) {
+    a.part_keys[2 * t] = KEY_INVALID;
+    a.part_keys[2 * t + 1] = KEY_INVALID;
+  }
+  u32 cur = KEY_INVALID;
+  bool first_run = true;
+  Xyzz acc = xyzz_identity();
+  for (size_t e = lo; e < hi; ++e) {
+    const u32 k = a.keys[e];
+    if (k == KEY_INVALID) continue;  // hole
+    if (k != cur) {
+      if (cur != KEY_INVALID) {
+        if (a.final_level || !first_run) {
+          st_xyzz(a.buckets, cur, acc);
+        } else {
+          a.part_keys[2 * t] = cur;
+          st_xyzz(a.part_pts, 2 * t, acc);
+        }
+        first_run = false;
+      }
+      cur = k;
+      acc = xyzz_identity();
+    }
+    acc = xyzz_add(acc, ld_xyzz(a.pts_in, e));
+  }
+  if (cur != KEY_INVALID) {
+    if (a.final_level) {
+      st_xyzz(a.buckets, cur, acc);
+    } else {  // the last run (possibly the only one) may continue in the next chunk
+      a.part_keys[2 * t + 1] = cur;
+      st_xyzz(a.part_pts, 2 * t + 1, acc);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ 4: bucket reduce
@@ -202,28 +307,20 @@ __global__ void __launch_bounds__(64) msm_bucket_chunk_kernel(const u32x4* bucke
   sum = xyzz_add(sum, xyzz_mul_small(running, b0));
   st_xyzz(red, gid, sum);
 }
-// out[w] = sum_t red[w * nt + t]   (one 64-thread workgroup per window, tree through LDS)
-__global__ void __launch_bounds__(64) msm_window_sum_kernel(const u32x4* red, u32 nt, u32x4* out) {
-  __shared__ u32x4 sh[64 * 16];
-  const u32 w = blockIdx.x, tid = threadIdx.x;
+// Sum of `per` consecutive entries per wave: out[g] = sum in[g*per .. (g+1)*per).  One wave per
+// workgroup (the group law wants the whole register file): each lane adds per/64 entries, then a
+// shuffle tree.  `finalize` reduces the coordinates below 2p for the host.
+__global__ void __launch_bounds__(64) msm_sum_kernel(const u32x4* in, u32 per, u32x4* out, u32 finalize) {
+  const u32 g = blockIdx.x, lane = threadIdx.x;
   Xyzz acc = xyzz_identity();
-  for (u32 i = tid; i < nt; i += 64) acc = xyzz_add(acc, ld_xyzz(red, (size_t)w * nt + i));
-  st_xyzz(sh, tid, acc);
-  __syncthreads();
-  for (u32 s = 32; s > 0; s >>= 1) {
-    if (tid < s) {
-      acc = xyzz_add(ld_xyzz(sh, tid), ld_xyzz(sh, tid + s));
-    }
-    __syncthreads();
-    if (tid < s) st_xyzz(sh, tid, acc);
-    __syncthreads();
-  }
-  if (tid == 0) {
-    if (!acc.inf) {  // hand the host values below 2p (they must fit 384 bits)
+  for (u32 i = lane; i < per; i += 64) acc = xyzz_add(acc, ld_xyzz(in, (size_t)g * per + i));
+  for (int d = 32; d > 0; d >>= 1) acc = xyzz_add(acc, xyzz_shfl_down(acc, d));
+  if (lane == 0) {
+    if (finalize && !acc.inf) {  // the host needs values that fit 384 bits
       acc.x = fe_mul<FpP>(acc.x, fe_one<FpP>());
       acc.y = fe_mul<FpP>(acc.y, fe_one<FpP>());
     }
-    st_xyzz(out, w, acc);
+    st_xyzz(out, g, acc);
   }
 }
 
@@ -299,22 +396,27 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
   const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits);
   const size_t m = n * g.nwin;  // (key, value) pairs
-  const u32 L1 = 32, LN = 16;
-  // level sizes
+  // chunk sizes: level 1 reads L1 sorted pairs per thread; deeper levels read LN slots of the
+  // (mostly empty) partial list, shifted by LN/2 so that the two slots a wave boundary leaves
+  // behind (tail of lane 63, head of the next lane 0) fall into the same chunk
+  // L1 up to 128 (measured, profiles/r01_msm_sweep.txt): at 2^20 points shorter chunks run the big
+  // kernel ~5 % faster (more rounds of waves) but leave 7x more partials for the latency-bound
+  // follow-up levels; 128 is the better total as long as the grid still has >= 2^17 threads
+  const u32 L1 = ctx->opt_msm_chunk ? (u32)ctx->opt_msm_chunk : (u32)std::max<size_t>(16, std::min<size_t>(128, m >> 17));
+  const u32 LN = 8, LN_OFF = 4;
   std::vector<size_t> lens;  // lens[0] = m (level 1 input), lens[i] = partial list length
   lens.push_back(m);
   {
-    size_t len = m, chunk = L1;
-    while (true) {
-      size_t nthr = (len + chunk - 1) / chunk;
-      if (nthr <= 1) break;
-      len = 2 * nthr;
+    size_t nthr = (m + L1 - 1) / L1;
+    while (nthr > 1) {
+      const size_t len = 2 * nthr;
       lens.push_back(len);
-      chunk = LN;
+      nthr = (len + LN_OFF + LN - 1) / LN;
+      if (len <= 32) break;  // the next level is a single thread
     }
   }
   const size_t total_buckets = (size_t)g.nbuckets * g.nwin;
-  const u32 LB = std::min<u32>(32, g.nbuckets);
+  const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : 8u, g.nbuckets);
   const u32 chunks_per_win = g.nbuckets / LB;
   const size_t total_chunks = (size_t)chunks_per_win * g.nwin;
 
@@ -337,6 +439,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     o_ppts[i] = take(lens[i] * 256);
   }
   const size_t o_red = take(total_chunks * 256);
+  const size_t o_red2 = take((total_chunks / 256 + g.nwin) * 256);
   const size_t o_win = take((size_t)g.nwin * 256);
   int rc = ensure_buffer(ctx, ctx->msm_ws, off);
   if (rc) return rc;
@@ -375,7 +478,10 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     const bool last = (lvl + 1 == lens.size());
     a.len = lens[lvl];
     a.chunk = lvl == 0 ? L1 : LN;
-    if (last) a.chunk = (u32)std::max<size_t>(a.chunk, a.len);  // one thread takes what is left
+    a.offset = lvl == 0 ? 0 : LN_OFF;
+    if (last) {  // one thread takes what is left
+      a.chunk = (u32)std::max<size_t>(a.chunk, a.len + a.offset);
+    }
     a.final_level = last ? 1u : 0u;
     if (lvl == 0) {
       a.keys = keys1;
@@ -388,25 +494,38 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
       a.part_keys = (u32*)(ws + o_pkeys[lvl + 1]);
       a.part_pts = (u32x4*)(ws + o_ppts[lvl + 1]);
     }
-    const size_t nthr = (a.len + a.chunk - 1) / a.chunk;
+    const size_t nthr = (a.len + a.offset + a.chunk - 1) / a.chunk;
     const unsigned blocks = (unsigned)((nthr + 127) / 128);
     {
       ProfScope prof(ctx, st, lvl == 0 ? "msm_accumulate_l1" : "msm_accumulate_ln");
       if (lvl == 0)
-        hipLaunchKernelGGL((msm_accumulate_kernel<true>), dim3(blocks), dim3(128), 0, st, a);
+        hipLaunchKernelGGL(msm_accumulate_l1_kernel, dim3(blocks), dim3(128), 0, st, a);
       else
-        hipLaunchKernelGGL((msm_accumulate_kernel<false>), dim3(blocks), dim3(128), 0, st, a);
+        hipLaunchKernelGGL(msm_accumulate_ln_kernel, dim3(blocks), dim3(128), 0, st, a);
     }
     PM_HIP(ctx, hipGetLastError());
   }
   // 4 bucket reduce
   {
-  ProfScope prof(ctx, st, "msm_bucket_reduce");
+  ProfScope prof(ctx, st, "msm_bucket_chunk");
   hipLaunchKernelGGL(msm_bucket_chunk_kernel, dim3((unsigned)((total_chunks + 63) / 64)), dim3(64), 0, st,
                      (const u32x4*)buckets, g.nbuckets, LB, (u32)total_chunks, (u32x4*)(ws + o_red));
+  }
   PM_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(msm_window_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red),
-                     chunks_per_win, (u32x4*)(ws + o_win));
+  {
+    // two stages: 256 entries per wave, then what is left per window
+    ProfScope prof(ctx, st, "msm_window_sum");
+    const u32 per1 = std::min<u32>(256, chunks_per_win);
+    const u32 groups = chunks_per_win / per1;  // per window
+    if (groups > 1) {
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nwin * groups), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
+                         (u32x4*)(ws + o_red2), 0u);
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red2), groups,
+                         (u32x4*)(ws + o_win), 1u);
+    } else {
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
+                         (u32x4*)(ws + o_win), 1u);
+    }
   }
   PM_HIP(ctx, hipGetLastError());
   // 5 host fold
