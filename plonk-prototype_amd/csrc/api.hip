@@ -114,6 +114,7 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
       hipFree(kv.second.tw_lo);
       hipFree(kv.second.cs_hi);
       hipFree(kv.second.cs_lo);
+      for (void* t : kv.second.pass_tw) hipFree(t);
     }
   }
   for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws,
@@ -180,8 +181,13 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_msm_lb = value;
     return PM_OK;
   }
+  if (!strcmp(key, "ntt_max_radix")) {
+    if (value < 6 || value > 10) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_max_radix must be 6..10");
+    ctx->opt_ntt_max_radix = value;
+    return PM_OK;
+  }
   if (!strcmp(key, "ntt_tile_log")) {
-    if (value != 11 && value != 12) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_tile_log must be 11 or 12");
+    if (value != 0 && value != 11 && value != 12) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_tile_log must be 0 (auto), 11 or 12");
     ctx->opt_ntt_tile_log = value;
     return PM_OK;
   }

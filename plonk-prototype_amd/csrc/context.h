@@ -21,6 +21,7 @@ struct NttDomainTables {  // per (log_n, direction)
   void* tw_lo = nullptr;
   void* cs_hi = nullptr;
   void* cs_lo = nullptr;
+  void* pass_tw[4] = {nullptr, nullptr, nullptr, nullptr};  // direct twiddles of pass i (wide planes)
   unsigned lh = 0;
 };
 
@@ -56,7 +57,8 @@ struct pm_ctx {
   std::map<std::string, ProfStat> prof_stats;
   // tunables
   long opt_msm_window_bits = 0;  // 0 = auto
-  long opt_ntt_tile_log = 11;
+  long opt_ntt_tile_log = 0;     // 0 = auto
+  long opt_ntt_max_radix = 10;   // log2 of the largest pass radix (multi-pass plans)
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
   int num_cus = 256;

@@ -120,6 +120,13 @@ struct Consts {
     }
     return x;
   }
+  // 2^(W N) - m in radix 2^W (all limbs < 2^W)
+  static PM_HD Limbs<N> rbar() {
+    Limbs<N> m = mod_limbs(), r{};
+    for (int i = 0; i < N; ++i) r.v[i] = MASK - m.v[i];
+    r.v[0] += 1;  // m is odd, so this cannot carry
+    return r;
+  }
   // k*m with every limb but the top biased by 2^(W+E) - 2^E so that a limb-wise
   // `a + bias - b` cannot go negative for b limbs < 2^(W+E) - 2^E (top limb: < top of k*m - 2^E)
   static PM_HD Limbs<N> sub_bias(u32 k, int E) {
@@ -278,6 +285,31 @@ PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
   }
   t.l[N - 1] = (u32)acc;
   return t;
+}
+
+// Cheap reduction without a Montgomery product: x (limbs < 2^32, value < 2^(W N)) -> normalised
+// limbs, same residue, value < m + m/2^16.  One-limb Barrett: q = floor(top(x) / (top(m)+1)) never
+// exceeds floor(x/m) and misses it by at most one; x - q m is formed as the low W N bits of
+// x + q (2^(W N) - m), so no borrow chain is needed.  ~4 VALU ops per limb.
+template <class P>
+PM_DEV Fe<P> fe_reduce_weak(const Fe<P>& x) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr Limbs<N> RB = Consts<P>::rbar();
+  constexpr u64 MAGIC = ((u64)1 << 52) / ((u64)M.v[N - 1] + 1);
+  const u32 top = x.l[N - 1] + (x.l[N - 2] >> W);
+  const u32 q = (u32)(((u64)top * MAGIC) >> 52);
+  Fe<P> r;
+  u64 acc = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    acc += (u64)q * RB.v[i];
+    acc += x.l[i];
+    r.l[i] = (u32)acc & MASK;
+    acc >>= W;
+  }
+  return r;
 }
 
 // compile-time constant 2^e mod m as an element (canonical limbs)

@@ -47,7 +47,7 @@ struct Plan {
   int S[4] = {0, 0, 0, 0};
   int LT[4] = {0, 0, 0, 0};
 };
-static Plan make_plan(unsigned log_n, int tile_log) {
+static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10) {
   Plan p;
   if (log_n < 3) return p;  // tiny kernel
   if (log_n <= 10) {
@@ -55,11 +55,13 @@ static Plan make_plan(unsigned log_n, int tile_log) {
     p.S[0] = (int)log_n;
     return p;
   }
-  p.npass = (int)((log_n + 9) / 10);
+  p.npass = (int)((log_n + max_radix - 1) / max_radix);
   int base = (int)log_n / p.npass, extra = (int)log_n % p.npass;
   for (int i = 0; i < p.npass; ++i) {
     p.S[i] = base + (i < extra ? 1 : 0);
-    int lt = tile_log - p.S[i];
+    // tile_log 0 = auto: 2^11-element tiles, but never fewer than 4 adjacent columns (runs of
+    // 64 B per limb plane): measured at 2^20, T = 2 -> 4 takes the last pass from 84 to 73 us
+    int lt = tile_log ? tile_log - p.S[i] : std::max(11 - p.S[i], 2);
     if (p.S[i] < 8) lt = 11 - p.S[i];  // 2^12-element tiles exist for S >= 8 only
     lt = std::min(lt, (int)log_n - p.S[i]);
     p.LT[i] = lt;
@@ -136,14 +138,10 @@ static int get_domain_tables(pm_ctx* ctx, int dir, unsigned log_n, bool need_cos
   }
   if (need_coset && !t.cs_lo) {
     HFr g = host::from_u64(host::FR_GENERATOR, F);
-    HFr mult = host::one(F);
-    if (dir) {
-      g = host::inv(g, F);
-      mult = host::inv(host::from_u64((u64)1 << log_n, F), F);  // size_inv folded into cs_hi
-    }
+    if (dir) g = host::inv(g, F);
     int rc = build_pow_table(ctx, &t.cs_lo, g, host::one(F), n_lo, 1, st);
     if (rc) return rc;
-    rc = build_pow_table(ctx, &t.cs_hi, g, mult, n_hi, n_lo, st);
+    rc = build_pow_table(ctx, &t.cs_hi, g, host::one(F), n_hi, n_lo, st);
     if (rc) return rc;
   }
   *out = &t;
@@ -210,9 +208,13 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
   a.lh = dt->lh;
 
   const u32 pre = (coset && !dir) ? PASS_PRE_COSET : 0u;
-  const u32 post = (coset && dir) ? PASS_POST_COSET : 0u;
+  // n^-1 of an inverse transform: folded into the last pass's twiddle table when there are two
+  // or more passes with direct tables; otherwise multiplied explicitly (PASS_POST_SCALE)
+  const bool direct_tw = log_n <= 26;  // tables of N x 36 B per twiddled pass and direction
 
-  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log);
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix);
+  const bool scale_folded = dir && plan.npass > 1 && direct_tw;
+  const u32 post = ((dir && !scale_folded) ? PASS_POST_SCALE : 0u) | ((dir && coset) ? PASS_POST_COSET : 0u);
   if (plan.npass == 0) {
     a.in = (const u32x4*)d_in;
     a.out = (u32x4*)d_out;
@@ -254,7 +256,22 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     a.batch_stride_out = (plan.npass == 1 && inplace) ? n : out_stride;
     a.in_len = (u32)in_len;
     a.log_ns = log_ns;
-    a.flags = (i == 0 ? pre : 0u) | (last ? post : 0u);
+    u32 post_i = last ? post : 0u;
+    a.pass_tw = nullptr;
+    u32 tw_flag = 0;
+    if (i > 0 && direct_tw) {
+      if (!dt->pass_tw[i]) {
+        PM_HIP(ctx, hipMalloc(&dt->pass_tw[i], n * 36));
+        NttConsts c2 = kc;
+        if (!(last && dir)) memcpy(c2.scale, kc.one, sizeof c2.scale);  // only the inverse's last pass carries n^-1
+        hipLaunchKernelGGL(pass_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dt->pass_tw[i], c2,
+                           log_n, log_ns, (u32)S, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh);
+        PM_HIP(ctx, hipGetLastError());
+      }
+      a.pass_tw = dt->pass_tw[i];
+      tw_flag = PASS_DIRECT_TW;
+    }
+    a.flags = (i == 0 ? pre : 0u) | post_i | tw_flag;
     const unsigned threads = std::max(64u, (1u << (S + LT)) / 8);
     const size_t lds = pass_lds_bytes(S, LT);
     if (lds > 64 * 1024)
@@ -284,7 +301,7 @@ using namespace pm;
 
 extern "C" int pm_ntt_plan(uint32_t log_n, uint32_t radix_log2[4], uint32_t* n_passes) {
   if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
-  Plan p = make_plan(log_n, 11);
+  Plan p = make_plan(log_n, 0);
   for (int i = 0; i < 4; ++i) radix_log2[i] = (uint32_t)p.S[i];
   *n_passes = (uint32_t)p.npass;
   return PM_OK;
@@ -310,7 +327,7 @@ extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
     return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   if (log_n == 0) return PM_OK;
-  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log);
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix);
   for (int dir = 0; dir < 2; ++dir) {
     NttDomainTables* dt;
     int rc = get_domain_tables(ctx, dir, log_n, true, &dt, ctx->stream);

@@ -41,8 +41,9 @@ struct NttPassArgs {
   const u32x4* step_tw;   // in-tile step twiddles for this S, 48 B per entry
   const u32x4* tw_hi;     // w_N^(x << lh)        x < N >> lh        (48 B entries)
   const u32x4* tw_lo;     // w_N^x                x < 1 << lh
-  const u32x4* cs_hi;     // coset powers g^(x << lh) (fwd) or n^-1 * g^-(x << lh) (inv)
+  const u32x4* cs_hi;     // coset powers g^(x << lh) (fwd) or g^-(x << lh) (inv)
   const u32x4* cs_lo;     // g^x / g^-x           x < 1 << lh
+  const void* pass_tw;    // PASS_DIRECT_TW: this pass's input twiddles as wide planes, element order
   unsigned long long batch_stride_in;   // elements between batch vectors (canonical side)
   unsigned long long batch_stride_out;
   unsigned long long wide_total;        // elements in one wide buffer plane (batch * N)
@@ -53,7 +54,10 @@ struct NttPassArgs {
   u32 flags;
 };
 enum : u32 {
+  PASS_DIRECT_TW = 1u,   // input twiddles come from pass_tw (one load) instead of hi*lo
   PASS_PRE_COSET = 2u,   // multiply input i by g^i (coset_fft)
+  PASS_POST_SCALE = 4u,  // multiply outputs by consts.scale (single-pass ifft; otherwise n^-1 is
+                         // folded into the last pass's twiddle table)
   PASS_POST_COSET = 8u,  // multiply output i by cs_hi/lo (coset_ifft; n^-1 folded in cs_hi)
 };
 
@@ -111,6 +115,21 @@ PM_DEV Fr fr_limbs(const u32* c) {
 // w^e from the two-level table: hi[e >> lh] * lo[e & mask]   -> (1, <2)
 PM_DEV Fr two_level(const u32x4* hi, const u32x4* lo, u32 e, u32 lh) {
   return fe_mul<FrP>(ld_tw(hi, e >> lh), ld_tw(lo, e & ((1u << lh) - 1u)));
+}
+
+// canonical limbs (value < r) for table entries: reduce a (1, <2) product fully
+PM_DEV Fr fr_canon(const Fr& a) {
+  u32 s[8];
+  fe_canon_pack<FrP>(s, a);
+  return fe_unpack<FrP>(s);
+}
+PM_DEV Fr fr_pow(Fr b, unsigned long long e, Fr acc) {
+  while (e) {
+    if (e & 1) acc = fe_mul<FrP>(acc, b);
+    b = fe_mul<FrP>(b, b);
+    e >>= 1;
+  }
+  return acc;
 }
 
 // (x, y) <- (x + y, x - y + K r);  y limbs <= 2^30 - 2, y value < (K-1) r
@@ -209,7 +228,7 @@ PM_DEV void ntt_step(Fr (&x)[8], const NttPassArgs& a, const NttConsts& kc, u32x
   if constexpr (Q == 8) {
     const u32 kp = u & (nsp - 1);
     if (STEP > 0) {
-      x[0] = fe_mul<FrP>(x[0], fr_limbs(kc.one));  // reduce the untwiddled input
+      x[0] = fe_reduce_weak<FrP>(x[0]);  // the untwiddled input: (<6, <40) -> (1, <1.01)
       x[1] = fe_mul<FrP>(x[1], ld_tw(stw, 0 * nsp + kp));
       x[2] = fe_mul<FrP>(x[2], ld_tw(stw, 1 * nsp + kp));
       x[3] = fe_mul<FrP>(x[3], ld_tw(stw, 2 * nsp + kp));
@@ -286,9 +305,11 @@ PM_DEV void ntt_step(Fr (&x)[8], const NttPassArgs& a, const NttConsts& kc, u32x
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const size_t go = obase + (size_t)(u + m * U) * ns;
-        Fr f = (a.flags & PASS_POST_COSET) ? two_level(a.cs_hi, a.cs_lo, (u32)go, a.lh)
-                                           : fr_limbs(kc.scale);
-        fe_store<FrP>(gout + 2 * go, fe_mul<FrP>(x[m], f));
+        Fr v = x[m];
+        if (a.flags & PASS_POST_SCALE) v = fe_mul<FrP>(v, fr_limbs(kc.scale));
+        if (a.flags & PASS_POST_COSET) v = fe_mul<FrP>(v, two_level(a.cs_hi, a.cs_lo, (u32)go, a.lh));
+        if (!(a.flags & (PASS_POST_SCALE | PASS_POST_COSET))) v = fe_reduce_weak<FrP>(v);
+        fe_store<FrP>(gout + 2 * go, v);
       }
     }
   }
@@ -330,11 +351,20 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 8 < 64 ? 64 : (1 << (S + LT)
       const size_t boff = (size_t)blockIdx.y * n;
       const u32 k = (u32)(j & (((size_t)1 << a.log_ns) - 1));
       const u32 tw_shift = log_n - a.log_ns - S;  // exponent stride N / (Ns R)
+      if (a.flags & PASS_DIRECT_TW) {
+        const WidePtr wtw = wide_ptrs(const_cast<void*>(a.pass_tw), n);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const u32 row = u + m * U;
-        Fr v = ld_wide(win, boff + j + (size_t)row * n_cols);                  // (<6, <40)
-        x[m] = fe_mul<FrP>(v, two_level(a.tw_hi, a.tw_lo, (k * row) << tw_shift, a.lh));
+        for (int m = 0; m < 8; ++m) {
+          const size_t idx = j + (size_t)(u + m * U) * n_cols;
+          x[m] = fe_mul<FrP>(ld_wide(win, boff + idx), ld_wide(wtw, idx));     // (<6, <40) * (1, <1)
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const u32 row = u + m * U;
+          Fr v = ld_wide(win, boff + j + (size_t)row * n_cols);                // (<6, <40)
+          x[m] = fe_mul<FrP>(v, fr_canon(two_level(a.tw_hi, a.tw_lo, (k * row) << tw_shift, a.lh)));
+        }
       }
     } else {
       const u32x4* gin = reinterpret_cast<const u32x4*>(a.in) + 2 * (size_t)blockIdx.y * a.batch_stride_in;
@@ -359,21 +389,6 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 8 < 64 ? 64 : (1 << (S + LT)
     ntt_step<S, LT, 2, OUT_UFAST, OUT_WIDE>(x, a, kc, lds0, lds1, lds2, w8_1, w8_2, w8_3, tid, j0);
   if constexpr (NSTEPS > 3)
     ntt_step<S, LT, 3, OUT_UFAST, OUT_WIDE>(x, a, kc, lds0, lds1, lds2, w8_1, w8_2, w8_3, tid, j0);
-}
-
-// canonical limbs (value < r) for table entries: reduce a (1, <2) product fully
-PM_DEV Fr fr_canon(const Fr& a) {
-  u32 s[8];
-  fe_canon_pack<FrP>(s, a);
-  return fe_unpack<FrP>(s);
-}
-PM_DEV Fr fr_pow(Fr b, unsigned long long e, Fr acc) {
-  while (e) {
-    if (e & 1) acc = fe_mul<FrP>(acc, b);
-    b = fe_mul<FrP>(b, b);
-    e >>= 1;
-  }
-  return acc;
 }
 
 // out[i] = mult * base^(i * stride)      (table builder; one thread per entry)
@@ -402,6 +417,20 @@ __global__ void step_tw_kernel(u32x4* out, const NttConsts c, u32 S) {
   }
 }
 
+// twiddles of one pass in element order: out[idx] = mult * w_N^((j mod Ns) * row * N/(Ns R)),
+// idx = j + row * N/R  (exactly the index the pass loads its input element with)
+__global__ void pass_tw_kernel(void* out, const NttConsts c, u32 log_n, u32 log_ns, u32 S, const u32x4* tw_hi,
+                               const u32x4* tw_lo, u32 lh) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)1 << log_n;
+  if (idx >= n) return;
+  const u32 j = (u32)(idx & ((n >> S) - 1)), row = (u32)(idx >> (log_n - S));
+  const u32 k = j & ((1u << log_ns) - 1);
+  const u32 e = (k * row) << (log_n - log_ns - S);
+  Fr v = fe_mul<FrP>(two_level(tw_hi, tw_lo, e, lh), fr_limbs(c.scale));
+  st_wide(wide_ptrs(out, n), idx, fr_canon(v));
+}
+
 // log_n < 3: direct evaluation, one thread per output
 __global__ void ntt_tiny_kernel(const NttPassArgs a, const NttConsts kc) {
   const u32 n = 1u << a.log_n;
@@ -419,8 +448,9 @@ __global__ void ntt_tiny_kernel(const NttPassArgs a, const NttConsts kc) {
   }
   __syncthreads();  // in-place safe: every read precedes every write (one block per vector)
   if (j < n) {
-    Fr f = (a.flags & PASS_POST_COSET) ? two_level(a.cs_hi, a.cs_lo, j, a.lh) : fr_limbs(kc.scale);
-    fe_store<FrP>(gout + 2 * j, fe_mul<FrP>(acc, f));
+    acc = fe_mul<FrP>(acc, fr_limbs(kc.scale));  // n^-1 (inverse) or one (forward): also the reduction
+    if (a.flags & PASS_POST_COSET) acc = fe_mul<FrP>(acc, two_level(a.cs_hi, a.cs_lo, j, a.lh));
+    fe_store<FrP>(gout + 2 * j, acc);
   }
 }
 

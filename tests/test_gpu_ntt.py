@@ -34,15 +34,19 @@ def test_every_plan_against_oracle(ctx, oracle, k):
             assert np.array_equal(ctx.fr_ntt(a[:in_len], k, flags), oracle.fr_ntt(a[:in_len], k, flags, 8))
 
 
-@pytest.mark.parametrize("k", [12, 16, 20])
-def test_tile_option_12(ctx, oracle, k):
+@pytest.mark.parametrize("k,tile,maxr", [(12, 12, 10), (16, 11, 10), (16, 12, 8), (20, 11, 10), (20, 12, 10),
+                                           (20, 11, 7), (18, 11, 6), (21, 12, 9)])
+def test_plan_options(ctx, oracle, k, tile, maxr):
+    """Every tile shape / pass split the tunables can select gives the same bits."""
     a = oracle.fr_sample(12 + k, 1 << k)
-    ctx.set_option("ntt_tile_log", 12)
+    ctx.set_option("ntt_tile_log", tile)
+    ctx.set_option("ntt_max_radix", maxr)
     try:
         for flags in ALL_FLAGS:
             assert np.array_equal(ctx.fr_ntt(a, k, flags), oracle.fr_ntt(a, k, flags, 8))
     finally:
-        ctx.set_option("ntt_tile_log", 11)
+        ctx.set_option("ntt_tile_log", 0)
+        ctx.set_option("ntt_max_radix", 10)
 
 
 @pytest.mark.parametrize("k", [2, 7, 10, 13, 20])

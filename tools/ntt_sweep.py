@@ -5,9 +5,10 @@ import numpy as np, torch
 import plonk_prototype_amd as pa
 ctx = pa.Context(0)
 st = torch.cuda.current_stream().cuda_stream
-def run(k, batch, flags, tile, reps=10):
+def run(k, batch, flags, tile, reps=10, maxr=10):
     n = 1 << k
     ctx.set_option("ntt_tile_log", tile)
+    ctx.set_option("ntt_max_radix", maxr)
     a = torch.randint(0, 2**31, (batch * n * 4,), dtype=torch.int64, device="cuda")  # not canonical; timing only
     a &= (1 << 60) - 1
     b = torch.empty_like(a)
@@ -23,10 +24,8 @@ def run(k, batch, flags, tile, reps=10):
     prof = ctx.profile_read(); ctx.profile(False)
     ks = {s: round(v[1] / v[0] * 1e3, 1) for s, v in prof.items()}
     bf = batch * (n // 2) * k / dt
-    print(f"k={k} batch={batch} flags={flags} tile={tile}: {dt*1e6:8.1f} us/call  {bf:.3e} butterflies/s  kernels_us={ks}", flush=True)
-for k in (12, 16, 18, 20, 22, 24):
-    for batch in (1, 4):
-        if (batch << k) > (1 << 26): continue
-        for tile in (11, 12):
-            run(k, batch, 0, tile)
-run(20, 1, 1, 11); run(20, 1, 2, 11); run(20, 1, 3, 11); run(22, 1, 2, 11); run(22,1,3,11)
+    print(f"k={k} batch={batch} flags={flags} tile={tile} maxr={maxr}: {dt*1e6:8.1f} us/call  {bf:.3e} butterflies/s  kernels_us={ks}", flush=True)
+for k in (16, 18, 20, 21, 22, 24):
+    for maxr in (10, 9, 8, 7, 6):
+        run(k, 1, 0, 11, maxr=maxr)
+run(20, 1, 0, 12, maxr=10); run(20, 4, 0, 11, maxr=7); run(20, 4, 0, 12, maxr=10)
