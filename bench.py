@@ -156,7 +156,8 @@ def main():
                "roofline": {"bound": "hbm", "kernel": "msm_accumulate_l1",
                             "achieved": round(128 * (hi - lo) / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
                             "unit": "GB/s", "frac": round(128 * (hi - lo) / (acc_ms * 1e-3) / HBM_PEAK, 5),
-                            "traffic": None}}
+                            "traffic": (json.load(open(tpath)).get(f"msm_accumulate_l1_2^{mk}")
+                                        if os.path.exists(tpath) and world == 1 else None)}}
         assert ok, "MSM result differs from the discrete-log identity"
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)

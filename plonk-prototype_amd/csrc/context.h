@@ -22,6 +22,7 @@ struct NttDomainTables {  // per (log_n, direction)
   void* cs_hi = nullptr;
   void* cs_lo = nullptr;
   void* pass_tw[4] = {nullptr, nullptr, nullptr, nullptr};  // direct twiddles of pass i (wide planes)
+  unsigned pass_tw_key[4] = {0, 0, 0, 0};                   // (log_ns << 8 | S) << 1 | last: what it was built for
   unsigned lh = 0;
 };
 

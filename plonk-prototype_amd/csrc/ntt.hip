@@ -237,6 +237,11 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
   const void* src = d_in;
   unsigned log_ns = 0;
   a.wide_total = (unsigned long long)batch * n;
+  {
+    int min_lt = 3;
+    for (int i = 0; i < plan.npass; ++i) min_lt = std::min(min_lt, plan.LT[i]);
+    a.wide_glog = (u32)std::max(min_lt, 2);
+  }
   for (int i = 0; i < plan.npass; ++i) {
     const bool last = (i == plan.npass - 1);
     const int S = plan.S[i], LT = plan.LT[i];
@@ -260,12 +265,19 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     a.pass_tw = nullptr;
     u32 tw_flag = 0;
     if (i > 0 && direct_tw) {
+      const unsigned key = (((((log_ns << 8) | (unsigned)S) << 1) | (last ? 1u : 0u)) << 2) | a.wide_glog;
+      if (dt->pass_tw[i] && dt->pass_tw_key[i] != key) {  // the plan changed (tunables): rebuild
+        PM_HIP(ctx, hipStreamSynchronize(st));
+        PM_HIP(ctx, hipFree(dt->pass_tw[i]));
+        dt->pass_tw[i] = nullptr;
+      }
       if (!dt->pass_tw[i]) {
+        dt->pass_tw_key[i] = key;
         PM_HIP(ctx, hipMalloc(&dt->pass_tw[i], n * 36));
         NttConsts c2 = kc;
         if (!(last && dir)) memcpy(c2.scale, kc.one, sizeof c2.scale);  // only the inverse's last pass carries n^-1
         hipLaunchKernelGGL(pass_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dt->pass_tw[i], c2,
-                           log_n, log_ns, (u32)S, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh);
+                           log_n, log_ns, (u32)S, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, a.wide_glog);
         PM_HIP(ctx, hipGetLastError());
       }
       a.pass_tw = dt->pass_tw[i];

@@ -16,7 +16,7 @@
 // through LDS (limb planes of 16+16+4 bytes so consecutive lanes hit consecutive banks).
 //
 // Number representation (fields.cuh): 9 x 29-bit limbs, lazily reduced.  Between passes the
-// vector lives in HBM in the same 9-limb "wide" form (three planes, 36 B/element), so only
+// vector lives in HBM in the same 9-limb "wide" form (36 B/element, blocked by 4), so only
 // the first load unpacks canonical data and only the last store canonicalises.
 //
 // Bounds are written (B, V): limbs < B*2^29, value < V*r.  fe_mul needs its left operand at
@@ -46,7 +46,8 @@ struct NttPassArgs {
   const void* pass_tw;    // PASS_DIRECT_TW: this pass's input twiddles as wide planes, element order
   unsigned long long batch_stride_in;   // elements between batch vectors (canonical side)
   unsigned long long batch_stride_out;
-  unsigned long long wide_total;        // elements in one wide buffer plane (batch * N)
+  unsigned long long wide_total;        // elements in one wide buffer (batch * N)
+  u32 wide_glog;          // log2 of the wide layout's block size (2 or 3)
   u32 in_len;             // elements present in `in`; the rest of the domain reads as zero
   u32 log_n;
   u32 log_ns;             // log2(Ns)
@@ -78,31 +79,42 @@ PM_DEV void st_tw(u32x4* tab, size_t idx, const Fr& v) {
   p[1] = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
   p[2] = u32x4{v.l[8], 0u, 0u, 0u};
 }
-// ---- wide vectors: plane0[total] (limbs 0-3), plane1[total] (4-7), plane2[total] (limb 8) --
+// ---- wide vectors: 9 limbs per element, 36 B/element, blocked by G = 4 or 8 elements: each group
+// of G consecutive elements is one 36 G-byte block [G x limbs 0-3 | G x limbs 4-7 | G x limb 8]
+// (G = the smallest tile width T of the plan, so a lane group reads whole blocks).
+// A pass touches groups of T >= 4 adjacent columns, so the three 16/16/4-byte pieces of a lane
+// quad land in the same one or two cache lines.  (Measured alternatives at 2^20 / 2^24: three
+// separate limb planes fetch 2.3x the ideal bytes and make the 2^24 passes HBM-bound; 48-byte
+// records coalesce but move 33 % more bytes and lose 10 % at 2^24.)
 struct WidePtr {
-  u32x4* p0;
-  u32x4* p1;
-  u32* p2;
+  u32x4* p;
+  u32 glog;  // log2 of the block's element count (2 or 3)
 };
-PM_DEV WidePtr wide_ptrs(void* base, size_t total) {
+PM_DEV WidePtr wide_ptrs(void* base, u32 glog) {
   WidePtr w;
-  w.p0 = reinterpret_cast<u32x4*>(base);
-  w.p1 = w.p0 + total;
-  w.p2 = reinterpret_cast<u32*>(w.p1 + total);
+  w.p = reinterpret_cast<u32x4*>(base);
+  w.glog = glog;
   return w;
 }
 PM_DEV Fr ld_wide(const WidePtr& w, size_t i) {
-  u32x4 a = w.p0[i], b = w.p1[i];
+  const u32 G = 1u << w.glog;
+  const u32x4* q = w.p + (size_t)(9 * G / 4) * (i >> w.glog);
+  const u32 e = (u32)i & (G - 1);
+  u32x4 a = q[e], b = q[G + e];
+  u32 c = reinterpret_cast<const u32*>(q + 2 * G)[e];
   Fr r;
   r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
   r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  r.l[8] = w.p2[i];
+  r.l[8] = c;
   return r;
 }
 PM_DEV void st_wide(const WidePtr& w, size_t i, const Fr& v) {
-  w.p0[i] = u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
-  w.p1[i] = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
-  w.p2[i] = v.l[8];
+  const u32 G = 1u << w.glog;
+  u32x4* q = w.p + (size_t)(9 * G / 4) * (i >> w.glog);
+  const u32 e = (u32)i & (G - 1);
+  q[e] = u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+  q[G + e] = u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+  reinterpret_cast<u32*>(q + 2 * G)[e] = v.l[8];
 }
 
 PM_DEV Fr fr_limbs(const u32* c) {
@@ -296,7 +308,7 @@ PM_DEV void ntt_step(Fr (&x)[8], const NttPassArgs& a, const NttConsts& kc, u32x
     const size_t k = j & (ns - 1);
     const size_t obase = (j - k) * R + k;
     if constexpr (OUT_WIDE) {
-      const WidePtr wout = wide_ptrs(a.out, a.wide_total);
+      const WidePtr wout = wide_ptrs(a.out, a.wide_glog);
       const size_t boff = (size_t)blockIdx.y * n;
 #pragma unroll
       for (int m = 0; m < 8; ++m) st_wide(wout, boff + obase + (size_t)(u + m * U) * ns, x[m]);
@@ -347,12 +359,12 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 8 < 64 ? 64 : (1 << (S + LT)
     const u32 u = ufast ? tid % U : tid >> LT;
     const size_t j = j0 + c;
     if constexpr (IN_WIDE) {
-      const WidePtr win = wide_ptrs(const_cast<void*>(a.in), a.wide_total);
+      const WidePtr win = wide_ptrs(const_cast<void*>(a.in), a.wide_glog);
       const size_t boff = (size_t)blockIdx.y * n;
       const u32 k = (u32)(j & (((size_t)1 << a.log_ns) - 1));
       const u32 tw_shift = log_n - a.log_ns - S;  // exponent stride N / (Ns R)
       if (a.flags & PASS_DIRECT_TW) {
-        const WidePtr wtw = wide_ptrs(const_cast<void*>(a.pass_tw), n);
+        const WidePtr wtw = wide_ptrs(const_cast<void*>(a.pass_tw), a.wide_glog);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const size_t idx = j + (size_t)(u + m * U) * n_cols;
@@ -420,7 +432,7 @@ __global__ void step_tw_kernel(u32x4* out, const NttConsts c, u32 S) {
 // twiddles of one pass in element order: out[idx] = mult * w_N^((j mod Ns) * row * N/(Ns R)),
 // idx = j + row * N/R  (exactly the index the pass loads its input element with)
 __global__ void pass_tw_kernel(void* out, const NttConsts c, u32 log_n, u32 log_ns, u32 S, const u32x4* tw_hi,
-                               const u32x4* tw_lo, u32 lh) {
+                               const u32x4* tw_lo, u32 lh, u32 glog) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)1 << log_n;
   if (idx >= n) return;
@@ -428,7 +440,7 @@ __global__ void pass_tw_kernel(void* out, const NttConsts c, u32 log_n, u32 log_
   const u32 k = j & ((1u << log_ns) - 1);
   const u32 e = (k * row) << (log_n - log_ns - S);
   Fr v = fe_mul<FrP>(two_level(tw_hi, tw_lo, e, lh), fr_limbs(c.scale));
-  st_wide(wide_ptrs(out, n), idx, fr_canon(v));
+  st_wide(wide_ptrs(out, glog), idx, fr_canon(v));
 }
 
 // log_n < 3: direct evaluation, one thread per output

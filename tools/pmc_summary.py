@@ -22,5 +22,21 @@ for kname, ctrs in acc.items():
         s["hbm_bytes_per_launch_corrected"] = (2 * s["FETCH_SIZE"]["mean"] + s["WRITE_SIZE"]["mean"]) * 1024
         s["hbm_bytes_per_launch_raw"] = (s["FETCH_SIZE"]["mean"] + s["WRITE_SIZE"]["mean"]) * 1024
 json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
+# bench.py reads profiles/ntt_traffic.json: {"<role>_2^<k>": corrected HBM bytes per launch}
+import re
+traffic = {}
+roles = {("true", "false", "true"): "ntt_pass_first", ("false", "true", "true"): "ntt_pass_middle",
+         ("false", "true", "false"): "ntt_pass_last", ("false", "false", "false"): "ntt_pass_single"}
+log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+for k, v in summary.items():
+    m = re.match(r"pm::ntt_pass_kernel<(\d+), (\d+), (\w+), (\w+), (\w+)>", k)
+    if m and "hbm_bytes_per_launch_corrected" in v:
+        traffic[f"{roles[(m.group(3), m.group(4), m.group(5))]}_2^{log_n}"] = int(v["hbm_bytes_per_launch_corrected"])
+for k, v in summary.items():
+    if k.startswith("pm::msm_accumulate_l1") and "hbm_bytes_per_launch_corrected" in v:
+        traffic[f"msm_accumulate_l1_2^{log_n}"] = int(v["hbm_bytes_per_launch_corrected"])
+if traffic:
+    json.dump(traffic, open(os.path.join(os.path.dirname(out), "ntt_traffic.json"), "w"), indent=1, sort_keys=True)
+    print("traffic:", traffic)
 for k, v in sorted(summary.items()):
     print(k, {c: (round(x["mean"]) if isinstance(x, dict) else round(x)) for c, x in v.items()})
