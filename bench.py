@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--msm-log-n", type=int, default=20)
     ap.add_argument("--msm-steps", type=int, default=5)
+    ap.add_argument("--msm-large-log-n", type=int, default=24,
+                    help="second MSM leg (BASELINE configs[4]); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true")
     args = ap.parse_args()
@@ -117,16 +119,18 @@ def main():
                 "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()},
                 "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
 
-    # ------------------------------------------------------------------ MSM leg
-    msm = None
-    if not args.no_msm:
-        mk = args.msm_log_n
+    # ------------------------------------------------------------------ MSM legs
+    tpath_exists = os.path.exists(tpath)
+    k0, dd = 0x1234567, 0xabcdef123456789abcdef
+
+    def run_msm(mk, steps):
+        """KZG-commit shaped MSM of 2^mk points, sharded by points over the ranks."""
         mn = 1 << mk
         lo, hi = shard_range(mn, rank, world)
-        k0, dd = 0x1234567, 0xabcdef123456789abcdef
-        k0_shard = ints_to_limbs([(k0 + lo * dd) % R_MOD], 4)[0]     # P_i = (k0 + i d) G, i in shard
+        k0_shard = ints_to_limbs([(k0 + lo * dd) % R_MOD], 4)[0]          # P_i = (k0 + i d) G, i in shard
         pts = oracle.g1_bases_arith(k0_shard, ints_to_limbs([dd], 4)[0], hi - lo, cores)
-        sc = oracle.fr_sample(0x5343414C, mn)[lo:hi]
+        full_sc = oracle.fr_sample(0x5343414C, mn)
+        sc = full_sc[lo:hi]
         bases = pa.host.Bases(ctx, pts)
         d_sc = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).to(dev)
 
@@ -138,27 +142,34 @@ def main():
         barrier()
         ctx.profile(True)
         t0 = time.perf_counter()
-        for _ in range(args.msm_steps):
+        for _ in range(steps):
             res = msm_step()
         barrier()
         mdt = max_over_ranks(time.perf_counter() - t0)
         mprof = ctx.profile_read()
         ctx.profile(False)
         # parity inside the bench: discrete-log identity (bases are known multiples of G)
-        full_sc = oracle.fr_sample(0x5343414C, mn)
         dl = oracle.expected_dlog(full_sc, 0, ints_to_limbs([k0], 4)[0], ints_to_limbs([dd], 4)[0])
         ok = bool(np.array_equal(pa.g1_to_affine(res)[0], oracle.g1_mul(oracle.g1_generator(), dl)))
         acc_ms = mprof["msm_accumulate_l1"][1] / mprof["msm_accumulate_l1"][0]
-        msm = {"metric": "bls12_381_g1_msm_scalar_muls_per_s", "value": mn * args.msm_steps / mdt,
-               "unit": "scalar-muls/s", "points": mn, "ms_per_msm": mdt / args.msm_steps * 1e3,
+        out = {"metric": "bls12_381_g1_msm_scalar_muls_per_s", "value": mn * steps / mdt,
+               "unit": "scalar-muls/s", "points": mn, "ms_per_msm": mdt / steps * 1e3,
                "scaling": "strong" if world > 1 else None, "bit_exact_vs_oracle": ok,
                "kernels_us": {s: round(v[1] / v[0] * 1e3, 1) for s, v in mprof.items()},
                "roofline": {"bound": "hbm", "kernel": "msm_accumulate_l1",
                             "achieved": round(128 * (hi - lo) / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
                             "unit": "GB/s", "frac": round(128 * (hi - lo) / (acc_ms * 1e-3) / HBM_PEAK, 5),
                             "traffic": (json.load(open(tpath)).get(f"msm_accumulate_l1_2^{mk}")
-                                        if os.path.exists(tpath) and world == 1 else None)}}
+                                        if tpath_exists and world == 1 else None)}}
         assert ok, "MSM result differs from the discrete-log identity"
+        bases.free()
+        return out, pts, sc
+
+    msm = msm_large = None
+    if not args.no_msm:
+        msm, pts, sc = run_msm(args.msm_log_n, args.msm_steps)
+        if args.msm_large_log_n > args.msm_log_n:
+            msm_large, _, _ = run_msm(args.msm_large_log_n, 2)
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     cpu = None
@@ -204,7 +215,7 @@ def main():
                "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "
                                       f"natural order in/out, bit-exact vs oracle", "log_n": k, "passes": passes,
                           "parallelism": f"{world} independent polynomial(s), one per GPU"},
-               "roofline": roofline, "cpu_baseline": cpu, "msm": msm}
+               "roofline": roofline, "cpu_baseline": cpu, "msm": msm, "msm_large": msm_large}
         print(json.dumps(out))
     ctx.close()
     if world > 1:

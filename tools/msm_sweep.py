@@ -28,6 +28,10 @@ def run(tag, **opts):
     print(f"{tag:34s} {dt*1e3:7.3f} ms  {ks}", flush=True)
     for kk in opts: ctx.set_option(kk, 0)
 run("default")
-for ch in (16, 32, 64, 128): run(f"chunk={ch}", msm_chunk=ch)
-for lb in (2, 4, 8, 16, 32): run(f"lb={lb}", msm_lb=lb)
-for c in (14, 15, 16, 17, 18): run(f"c={c}", msm_window_bits=c)
+if k <= 20:
+    for ch in (16, 32, 64, 128): run(f"chunk={ch}", msm_chunk=ch)
+    for lb in (2, 4, 8, 16, 32): run(f"lb={lb}", msm_lb=lb)
+    for c in (14, 15, 16, 17, 18): run(f"c={c}", msm_window_bits=c)
+else:
+    for c in (16, 17, 18, 19, 20): run(f"c={c}", msm_window_bits=c)
+    for ch in (64, 128, 256): run(f"chunk={ch}", msm_chunk=ch)
