@@ -133,6 +133,31 @@ int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]);
 /* Projective (homogeneous X/Z, Y/Z) -> affine; *is_identity = 1 and xy = 0 for infinity. */
 int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_identity);
 
+/* ---- device-resident polynomial helpers (the callers either side of the hot path) ------- */
+/* dusk_plonk::fft::{Polynomial, Evaluations} and
+ * util::batch_inversion as used by the prover rounds between the NTT and MSM calls.  All
+ * vectors are canonical Fr in DEVICE memory; `hip_stream` as in pm_fr_ntt_dev. */
+
+/* Device memory for callers without their own HIP allocator (the Rust prover, the tests). */
+int pm_dev_alloc(pm_ctx* ctx, size_t bytes, void** out);
+int pm_dev_free(pm_ctx* ctx, void* p);
+int pm_dev_upload(pm_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int pm_dev_download(pm_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* out[i] = a[i] (op) b[i]:  op 0 = add, 1 = sub, 2 = mul  (Evaluations / Polynomial `+ - *`).
+ * b_len == 1 broadcasts one scalar (Polynomial * scalar).  In place allowed. */
+int pm_fr_vec_op_dev(pm_ctx* ctx, int op, const void* d_a, const void* d_b, size_t b_len, void* d_out,
+                     size_t n, void* hip_stream);
+/* Polynomial::evaluate: out = sum_i coeffs[i] * point^i.  Blocks until `out` is on the host. */
+int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t point[4],
+                            uint64_t out[4], void* hip_stream);
+/* Polynomial::ruffini: quotient of coeffs(X) / (X - z), n-1 coefficients into d_out (the
+ * remainder coeffs(z) is dropped, as upstream).  Not in place.  Returns after the work finished. */
+int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], void* d_out,
+                           void* hip_stream);
+/* util::batch_inversion: every non-zero element is replaced by its inverse, zeros stay zero. */
+int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, void* hip_stream);
+
 /* ---- introspection / tuning (not needed by the prover) --------------------------------- */
 
 /* Number of kernel launches and the Stockham radices the library will use for 2^log_n. */

@@ -719,3 +719,55 @@ void orc_expected_dlog(const u64 *scalars, size_t n, unsigned scalar_form, const
   }
   fr_mul(out_canonical, acc, one);
 }
+
+/* ------------------------------------------------------------------ polynomial helpers (next rows N1/N2)
+ * Restatements of dusk_plonk::fft::{Polynomial, Evaluations} / util helpers the prover rounds use
+ * around the NTT/MSM calls (dusk-plonk 0.8.2 pinned at
+ * ref:Cargo.toml:19).  All vectors are Montgomery Fr (4 limbs). */
+/* Evaluations / Polynomial coefficient-wise ops: op 0 add, 1 sub, 2 mul; b_len == 1 broadcasts */
+void orc_fr_vec_op(int op, const u64 *a, const u64 *b, size_t b_len, u64 *out, size_t n) {
+  orc_init();
+  for (size_t i = 0; i < n; ++i) {
+    const u64 *y = b + 4 * (b_len == 1 ? 0 : i);
+    if (op == 0) fr_add(out + 4 * i, a + 4 * i, y);
+    else if (op == 1) fr_sub(out + 4 * i, a + 4 * i, y);
+    else fr_mul(out + 4 * i, a + 4 * i, y);
+  }
+}
+/* util::batch_inversion: zeros stay zero */
+void orc_fr_batch_inverse(u64 *v, size_t n) {
+  orc_init();
+  for (size_t i = 0; i < n; ++i)
+    if (!is_zero_n(v + 4 * i, 4)) f_inv(v + 4 * i, v + 4 * i, &FR);
+}
+/* Polynomial::evaluate: Horner */
+void orc_fr_poly_evaluate(const u64 *coeffs, size_t n, const u64 *point, u64 *out) {
+  orc_init();
+  u64 acc[4] = {0, 0, 0, 0};
+  for (size_t i = n; i-- > 0;) {
+    fr_mul(acc, acc, point);
+    fr_add(acc, acc, coeffs + 4 * i);
+  }
+  memcpy(out, acc, 32);
+}
+/* Polynomial::ruffini: quotient of division by (X - z); out has n-1 coefficients (n >= 1) */
+void orc_fr_poly_ruffini(const u64 *coeffs, size_t n, const u64 *z, u64 *out) {
+  orc_init();
+  u64 q[4] = {0, 0, 0, 0};
+  for (size_t i = n; i-- > 1;) {
+    u64 t[4];
+    fr_mul(t, q, z);
+    fr_add(q, t, coeffs + 4 * i);
+    memcpy(out + 4 * (i - 1), q, 32);
+  }
+}
+/* grand product of the permutation argument: out[0] = 1, out[i] = prod_{j<i} a[j] */
+void orc_fr_prefix_product(const u64 *a, size_t n, u64 *out) {
+  orc_init();
+  u64 acc[4];
+  memcpy(acc, FR.one, 32);
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(out + 4 * i, acc, 32);
+    fr_mul(acc, acc, a + 4 * i);
+  }
+}

@@ -69,6 +69,11 @@ class CpuOracle:
             "orc_g1_bases_arith": [_u64p, _u64p, C.c_size_t, _u64p, C.c_int],
             "orc_expected_dlog": [_u64p, C.c_size_t, C.c_uint, _u64p, _u64p, _u64p],
             "orc_constants": [_u64p, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p],
+            "orc_fr_vec_op": [C.c_int, _u64p, _u64p, C.c_size_t, _u64p, C.c_size_t],
+            "orc_fr_batch_inverse": [_u64p, C.c_size_t],
+            "orc_fr_poly_evaluate": [_u64p, C.c_size_t, _u64p, _u64p],
+            "orc_fr_poly_ruffini": [_u64p, C.c_size_t, _u64p, _u64p],
+            "orc_fr_prefix_product": [_u64p, C.c_size_t, _u64p],
         }.items():
             getattr(L, name).restype = None
             getattr(L, name).argtypes = at
@@ -139,6 +144,45 @@ class CpuOracle:
         if rc:
             raise ValueError(f"orc_fr_ntt rc={rc}")
         return buf
+
+    # ------------------------------------------------- Polynomial / Evaluations
+    def fr_vec_op(self, op: int, a, b) -> np.ndarray:
+        """op 0 add, 1 sub, 2 mul; b of one element broadcasts."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty_like(a)
+        if a.shape[0]:
+            self.lib.orc_fr_vec_op(op, _ptr(a), _ptr(b), b.shape[0], _ptr(out), a.shape[0])
+        return out
+
+    def fr_batch_inverse(self, a) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).copy()
+        if a.shape[0]:
+            self.lib.orc_fr_batch_inverse(_ptr(a), a.shape[0])
+        return a
+
+    def fr_poly_evaluate(self, coeffs, point) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        p = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+        out = np.zeros(4, np.uint64)
+        if c.shape[0]:
+            self.lib.orc_fr_poly_evaluate(_ptr(c), c.shape[0], _ptr(p), _ptr(out))
+        return out
+
+    def fr_poly_ruffini(self, coeffs, z) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
+        out = np.zeros((max(c.shape[0] - 1, 0), 4), np.uint64)
+        if c.shape[0] > 1:
+            self.lib.orc_fr_poly_ruffini(_ptr(c), c.shape[0], _ptr(zz), _ptr(out))
+        return out
+
+    def fr_prefix_product(self, a) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty_like(a)
+        if a.shape[0]:
+            self.lib.orc_fr_prefix_product(_ptr(a), a.shape[0], _ptr(out))
+        return out
 
     # ----------------------------------------------------------------------- G1
     def g1_generator(self) -> np.ndarray:

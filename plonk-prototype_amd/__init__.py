@@ -8,5 +8,6 @@ runs in hand-written HIP kernels; importing works without a GPU, but creating a
 """
 from ._lib import (BackendMissing, NTT_COSET, NTT_INVERSE, SCALAR_CANONICAL,  # noqa: F401
                    SCALAR_MONTGOMERY, load, LIB_PATH)
-from .host import (CommitKey, Context, Error, EvaluationDomain, msm_variable_base,  # noqa: F401
+from .host import (CommitKey, Context, DeviceVector, Error, EvaluationDomain, Polynomial,  # noqa: F401
+                   msm_variable_base,
                    g1_fold, g1_to_affine, domain_info, ntt_plan)

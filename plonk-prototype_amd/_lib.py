@@ -32,6 +32,15 @@ SIGNATURES = {
                                 C.c_uint32, u64p, C.c_void_p]),
     "pm_g1_fold": (C.c_int, [u64p, C.c_size_t, u64p]),
     "pm_g1_to_affine": (C.c_int, [u64p, u64p, C.POINTER(C.c_int)]),
+    "pm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pm_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pm_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pm_fr_vec_op_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.c_size_t, C.c_void_p]),
+    "pm_fr_poly_evaluate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_void_p]),
+    "pm_fr_poly_ruffini_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_void_p, C.c_void_p]),
+    "pm_fr_batch_inverse_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     "pm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

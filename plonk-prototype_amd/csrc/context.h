@@ -41,6 +41,7 @@ struct pm_ctx {
   // MSM workspaces
   pm::DeviceBuffer msm_ws;
   pm::DeviceBuffer msm_scalars;
+  pm::DeviceBuffer poly_ws;                             // scratch of the polynomial helpers
   void* msm_host_pinned = nullptr;
   size_t msm_host_pinned_bytes = 0;
   // opt-in per-kernel timing (hipEvents on the launch stream; read by bench.py)

@@ -404,7 +404,7 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 8 < 64 ? 64 : (1 << (S + LT)
 }
 
 // out[i] = mult * base^(i * stride)      (table builder; one thread per entry)
-__global__ void pow_table_kernel(u32x4* out, const NttConsts c, u32 count, u32 stride) {
+static __global__ void pow_table_kernel(u32x4* out, const NttConsts c, u32 count, u32 stride) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   Fr r = fr_pow(fr_limbs(c.w8[0]), (unsigned long long)i * stride, fr_limbs(c.scale));
@@ -412,7 +412,7 @@ __global__ void pow_table_kernel(u32x4* out, const NttConsts c, u32 count, u32 s
 }
 
 // step twiddles for radix 2^S: block s, entry [(t-1)*Ns' + k'] = w_{Ns' q}^(k' t) = wR^(k' t R/(Ns' q))
-__global__ void step_tw_kernel(u32x4* out, const NttConsts c, u32 S) {
+static __global__ void step_tw_kernel(u32x4* out, const NttConsts c, u32 S) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   u32 off = 0;
   for (u32 s = 0; 3 * s < S; ++s) {
@@ -431,7 +431,7 @@ __global__ void step_tw_kernel(u32x4* out, const NttConsts c, u32 S) {
 
 // twiddles of one pass in element order: out[idx] = mult * w_N^((j mod Ns) * row * N/(Ns R)),
 // idx = j + row * N/R  (exactly the index the pass loads its input element with)
-__global__ void pass_tw_kernel(void* out, const NttConsts c, u32 log_n, u32 log_ns, u32 S, const u32x4* tw_hi,
+static __global__ void pass_tw_kernel(void* out, const NttConsts c, u32 log_n, u32 log_ns, u32 S, const u32x4* tw_hi,
                                const u32x4* tw_lo, u32 lh, u32 glog) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)1 << log_n;
@@ -444,7 +444,7 @@ __global__ void pass_tw_kernel(void* out, const NttConsts c, u32 log_n, u32 log_
 }
 
 // log_n < 3: direct evaluation, one thread per output
-__global__ void ntt_tiny_kernel(const NttPassArgs a, const NttConsts kc) {
+static __global__ void ntt_tiny_kernel(const NttPassArgs a, const NttConsts kc) {
   const u32 n = 1u << a.log_n;
   const u32 j = threadIdx.x;
   const u32x4* gin = reinterpret_cast<const u32x4*>(a.in) + 2 * (size_t)blockIdx.y * a.batch_stride_in;

@@ -127,6 +127,104 @@ class Context:
         return out
 
 
+class DeviceVector:
+    """Canonical Fr vector in device memory (``pm_dev_alloc``): the currency of the polynomial
+    helpers.  ``DeviceVector.from_host(ctx, a)``, ``.to_host()``, ``.ptr`` (int)."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.n = ctx, n
+        h = C.c_void_p()
+        ctx._check(ctx._lib.pm_dev_alloc(ctx._h, max(n, 1) * 32, C.byref(h)))
+        self._p = h
+
+    @property
+    def ptr(self) -> int:
+        return self._p.value or 0
+
+    @classmethod
+    def from_host(cls, ctx: Context, a) -> "DeviceVector":
+        a = _fr(a)
+        v = cls(ctx, a.shape[0])
+        if a.shape[0]:
+            ctx._check(ctx._lib.pm_dev_upload(ctx._h, v._p, a.ctypes.data_as(C.c_void_p), a.shape[0] * 32))
+        return v
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty((self.n, 4), np.uint64)
+        if self.n:
+            self.ctx._check(self.ctx._lib.pm_dev_download(self.ctx._h, out.ctypes.data_as(C.c_void_p), self._p,
+                                                          self.n * 32))
+        return out
+
+    def free(self):
+        if getattr(self, "_p", None) and self.ctx._h:
+            self.ctx._lib.pm_dev_free(self.ctx._h, self._p)
+        self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Polynomial:
+    """``dusk_plonk::fft::Polynomial`` / ``Evaluations`` on the device: coefficient-wise
+    ``+ - *`` (a one-element operand is a scalar), ``evaluate`` and ``ruffini``; ``batch_inverse``
+    is ``util::batch_inversion``.  Thin wrappers over the ``pm_fr_*_dev`` entry points."""
+
+    OPS = {"add": 0, "sub": 1, "mul": 2}
+
+    def __init__(self, vec: DeviceVector):
+        self.vec = vec
+
+    @classmethod
+    def from_host(cls, ctx: Context, coeffs) -> "Polynomial":
+        return cls(DeviceVector.from_host(ctx, coeffs))
+
+    def to_host(self) -> np.ndarray:
+        return self.vec.to_host()
+
+    def _op(self, op: str, other: "Polynomial") -> "Polynomial":
+        ctx = self.vec.ctx
+        if other.vec.n not in (1, self.vec.n):
+            raise Error(_lib.PM_ERR_LENGTH, "operands differ in length")
+        out = DeviceVector(ctx, self.vec.n)
+        ctx._check(ctx._lib.pm_fr_vec_op_dev(ctx._h, self.OPS[op], self.vec._p, other.vec._p, other.vec.n, out._p,
+                                             self.vec.n, None))
+        return Polynomial(out)
+
+    def __add__(self, o):
+        return self._op("add", o)
+
+    def __sub__(self, o):
+        return self._op("sub", o)
+
+    def __mul__(self, o):
+        return self._op("mul", o)
+
+    def evaluate(self, point) -> np.ndarray:
+        ctx = self.vec.ctx
+        p = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+        out = np.zeros(4, np.uint64)
+        ctx._check(ctx._lib.pm_fr_poly_evaluate_dev(ctx._h, self.vec._p, self.vec.n, _p(p), _p(out), None))
+        return out
+
+    def ruffini(self, z) -> "Polynomial":
+        ctx = self.vec.ctx
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
+        out = DeviceVector(ctx, max(self.vec.n - 1, 0))
+        ctx._check(ctx._lib.pm_fr_poly_ruffini_dev(ctx._h, self.vec._p, self.vec.n, _p(zz), out._p, None))
+        return Polynomial(out)
+
+    def batch_inverse(self) -> "Polynomial":
+        """In place; returns self."""
+        ctx = self.vec.ctx
+        ctx._check(ctx._lib.pm_fr_batch_inverse_dev(ctx._h, self.vec._p, self.vec.n, None))
+        ctx.sync()
+        return self
+
+
 _default_ctx: Context | None = None
 
 

@@ -1,0 +1,81 @@
+"""Parity of the device-resident polynomial helpers (Polynomial /
+Evaluations ops, evaluate, ruffini, batch_inversion) with the oracle's restatements."""
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as B
+from oracle.cpu_oracle import ints_to_limbs, limbs_to_ints
+
+pytestmark = pytest.mark.gpu
+
+
+def _poly(ctx, a):
+    import plonk_prototype_amd as pa
+    return pa.Polynomial.from_host(ctx, a)
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 5000, 1 << 16, (1 << 18) + 3])
+def test_vec_ops(ctx, oracle, n):
+    a, b = oracle.fr_sample(1, n), oracle.fr_sample(2, n)
+    edge = oracle.fr_to_mont(ints_to_limbs([0, 1, B.R_MOD - 1], 4))
+    a[: min(n, 3)] = edge[: min(n, 3)]
+    b[-min(n, 3):] = edge[: min(n, 3)]
+    pa_, pb_ = _poly(ctx, a), _poly(ctx, b)
+    for op, py in ((0, pa_ + pb_), (1, pa_ - pb_), (2, pa_ * pb_)):
+        assert np.array_equal(py.to_host(), oracle.fr_vec_op(op, a, b)), (n, op)
+    s = _poly(ctx, b[:1])                                           # scalar broadcast
+    for op, py in ((0, pa_ + s), (1, pa_ - s), (2, pa_ * s)):
+        assert np.array_equal(py.to_host(), oracle.fr_vec_op(op, a, b[:1])), (n, op)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 256, 257, 4097, 1 << 16, (1 << 20) + 17])
+def test_evaluate(ctx, oracle, n):
+    c = oracle.fr_sample(3 + n, n)
+    for seed in (5, 6):
+        x = oracle.fr_sample(seed, 1)[0]
+        assert np.array_equal(_poly(ctx, c).evaluate(x), oracle.fr_poly_evaluate(c, x)), n
+    zero = np.zeros(4, np.uint64)
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+    assert np.array_equal(_poly(ctx, c).evaluate(zero), c[0] if n else zero)                 # p(0) = c_0
+    assert np.array_equal(_poly(ctx, c).evaluate(one), oracle.fr_poly_evaluate(c, one))      # p(1) = sum c_i
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 256, 257, 258, 5000, (1 << 16) + 1, (1 << 20) + 5])
+def test_ruffini(ctx, oracle, n):
+    c = oracle.fr_sample(7 + n, n)
+    for z in (oracle.fr_sample(9, 1)[0], np.zeros(4, np.uint64), oracle.fr_to_mont(ints_to_limbs([1], 4))[0]):
+        q = _poly(ctx, c).ruffini(z).to_host()
+        assert q.shape[0] == n - 1
+        assert np.array_equal(q, oracle.fr_poly_ruffini(c, z)), n
+    if n > 1:   # q(X) (X - z) + c(z) == c(X) at a random point (the defining identity)
+        z = oracle.fr_sample(9, 1)[0]
+        q = _poly(ctx, c).ruffini(z)
+        x = oracle.fr_sample(10, 1)[0]
+        xv, zv = limbs_to_ints(oracle.fr_from_mont(np.stack([x, z])))
+        qx, cx, cz = (limbs_to_ints(oracle.fr_from_mont(v.reshape(1, 4)))[0]
+                      for v in (q.evaluate(x), _poly(ctx, c).evaluate(x), _poly(ctx, c).evaluate(z)))
+        assert (qx * (xv - zv) + cz) % B.R_MOD == cx
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1 << 16, (1 << 18) + 11])
+def test_batch_inverse(ctx, oracle, n):
+    a = oracle.fr_sample(11 + n, n)
+    a[:: max(1, n // 7)] = 0                                       # zeros stay zero
+    if n > 5:
+        a[5] = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+        a[4] = oracle.fr_to_mont(ints_to_limbs([B.R_MOD - 1], 4))[0]
+    got = _poly(ctx, a).batch_inverse().to_host()
+    assert np.array_equal(got, oracle.fr_batch_inverse(a)), n
+    # a * a^-1 == 1 wherever a != 0
+    prod = (_poly(ctx, a) * _poly(ctx, got)).to_host()
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+    nz = a.any(axis=1)
+    assert np.array_equal(prod[nz], np.broadcast_to(one, (int(nz.sum()), 4))) and not prod[~nz].any()
+
+
+def test_errors(ctx, oracle):
+    import plonk_prototype_amd as pa
+    a, b = _poly(ctx, oracle.fr_sample(1, 10)), _poly(ctx, oracle.fr_sample(2, 7))
+    with pytest.raises(pa.Error) as e:
+        a + b
+    assert e.value.code == -6
