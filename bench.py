@@ -36,6 +36,7 @@ def main():
                     help="second MSM leg (BASELINE configs[4]); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--no-poly", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -171,6 +172,47 @@ def main():
         if args.msm_large_log_n > args.msm_log_n:
             msm_large, _, _ = run_msm(args.msm_large_log_n, 2)
 
+    # ------------------------------------------------------------------ next rows (N1/N2 helpers), rank 0
+    poly = None
+    if rank == 0 and not args.no_poly:
+        pk = 22
+        pn = 1 << pk
+        va = pa.DeviceVector.from_host(ctx, oracle.fr_sample(11, pn))
+        vb = pa.DeviceVector.from_host(ctx, oracle.fr_sample(12, pn))
+        vo = pa.DeviceVector(ctx, pn)
+        pt = oracle.fr_sample(13, 1)[0]
+        P, lib, h = pa.Polynomial, ctx._lib, ctx._h
+        import ctypes as C
+        pp = pt.ctypes.data_as(C.POINTER(C.c_uint64))
+        ev = np.zeros(4, np.uint64)
+
+        def timed(fn, reps=5):
+            fn()
+            ctx.sync()
+            ctx.profile(True)
+            for _ in range(reps):
+                fn()
+            ctx.sync()
+            pr = ctx.profile_read()
+            ctx.profile(False)
+            (name, (cnt, ms)), = pr.items()
+            return ms / reps * 1e-3
+
+        rows = {
+            "vec_add": (lambda: lib.pm_fr_vec_op_dev(h, 0, va._p, vb._p, pn, vo._p, pn, None), 96 * pn),
+            "vec_mul": (lambda: lib.pm_fr_vec_op_dev(h, 2, va._p, vb._p, pn, vo._p, pn, None), 96 * pn),
+            "poly_evaluate": (lambda: lib.pm_fr_poly_evaluate_dev(h, va._p, pn, pp, ev.ctypes.data_as(C.POINTER(C.c_uint64)), None), 32 * pn),
+            "poly_ruffini": (lambda: lib.pm_fr_poly_ruffini_dev(h, va._p, pn, pp, vo._p, None), 64 * pn),
+            "batch_inverse": (lambda: lib.pm_fr_batch_inverse_dev(h, vo._p, pn, None), 64 * pn),
+        }
+        poly = {"n": pn, "note": "SURVEY 8f rows N1/N2 helpers; algorithmic bytes = operands read once + result written once"}
+        for name, (fn, nbytes) in rows.items():
+            sec = timed(fn)
+            poly[name] = {"us": round(sec * 1e6, 1), "GB/s": round(nbytes / sec / 1e9, 1),
+                          "hbm_frac": round(nbytes / sec / HBM_PEAK, 4)}
+        for v in (va, vb, vo):
+            v.free()
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -215,7 +257,7 @@ def main():
                "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "
                                       f"natural order in/out, bit-exact vs oracle", "log_n": k, "passes": passes,
                           "parallelism": f"{world} independent polynomial(s), one per GPU"},
-               "roofline": roofline, "cpu_baseline": cpu, "msm": msm, "msm_large": msm_large}
+               "roofline": roofline, "cpu_baseline": cpu, "msm": msm, "msm_large": msm_large, "next_rows": poly}
         print(json.dumps(out))
     ctx.close()
     if world > 1:
