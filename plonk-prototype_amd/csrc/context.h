@@ -68,6 +68,8 @@ struct pm_ctx {
 
 struct pm_bases {
   void* d_xy = nullptr;  // n x 96 bytes, affine Montgomery, (0,0) = identity
+  void* d_table = nullptr;   // optional: ceil(256/table_c) rows of n points, row w = 2^(table_c w) * bases
+  unsigned table_c = 0;      // window bits the table was built for (0 = no table)
   size_t n = 0;
   int device = 0;
 };

@@ -42,26 +42,31 @@ static constexpr u32 KEY_INVALID = 0xffffffffu;
 
 struct MsmGeom {
   u32 c;         // window bits
-  u32 nwin;      // windows
+  u32 nwin;      // digit windows
+  u32 nsets;     // bucket sets: nwin, or 1 when the bases carry a table of 2^(c w) P
   u32 bbits;     // c - 1: bits of the bucket field
-  u32 nbuckets;  // 1 << bbits per window
-  u32 key_bits;  // bbits + bits(nwin)  (+1 so the trash key sorts last)
-  u32 trash;     // key of zero digits
+  u32 nbuckets;  // 1 << bbits per set
+  u32 key_bits;  // bits of a sort key (set || bucket, plus room for the trash key)
+  u32 trash;     // key of zero digits (sorts last)
+  u32 row_stride;  // table mode: points per table row (value = window * row_stride + index)
 };
 
-static MsmGeom make_geom(size_t n, long opt_c) {
+static MsmGeom make_geom(size_t n, long opt_c, u32 table_c, size_t table_stride) {
   MsmGeom g;
   u32 lg = 0;
   while (((size_t)1 << (lg + 1)) <= std::max<size_t>(n, 1)) ++lg;
   long c = opt_c ? opt_c : std::min<long>(16, std::max<long>(5, (long)lg - 4));
+  if (table_c) c = table_c;  // fixed when the table was built
   g.c = (u32)c;
   g.nwin = (256 + g.c - 1) / g.c;
+  g.nsets = table_c ? 1u : g.nwin;
   g.bbits = g.c - 1;
   g.nbuckets = 1u << g.bbits;
   u32 wb = 0;
-  while ((1u << wb) < g.nwin + 1) ++wb;  // room for window == nwin (trash)
+  while ((1u << wb) < g.nsets + 1) ++wb;  // room for set == nsets (trash)
   g.key_bits = g.bbits + wb;
-  g.trash = g.nwin << g.bbits;
+  g.trash = g.nsets << g.bbits;
+  g.row_stride = (u32)table_stride;
   return g;
 }
 
@@ -74,8 +79,74 @@ __global__ void bases_convert_kernel(const u32x4* in, u32x4* out, size_t n_coord
   fe_store<FpP>(out + 3 * i, fe_abi_to_dev<FpP>(v));
 }
 
+// Table of window multiples for a resident SRS: row w = 2^(c w) * bases.  One step doubles a row
+// c times in XYZZ (pass A, one point per thread, result to scratch) and normalises back to affine
+// with Montgomery's trick (pass B: `per` points per thread, taken with stride so that loads
+// coalesce, one Fermat inversion of the ZZZ product per thread).
+__global__ void __launch_bounds__(128) precompute_double_kernel(const u32x4* src, size_t n, u32 c, u32x4* scratch) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp x = fe_load<FpP>(src + 6 * i), y = fe_load<FpP>(src + 6 * i + 3);
+  u32 nz = 0;
+#pragma unroll
+  for (int k = 0; k < 14; ++k) nz |= x.l[k] | y.l[k];
+  Xyzz p = xyzz_identity();
+  if (nz) {
+    p = xyzz_double_affine(x, y);
+    for (u32 k = 1; k < c; ++k) p = xyzz_double(p);
+  }
+  st_xyzz(scratch, i, p);
+}
+__global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scratch, size_t n, u32 per, u32x4* prefix,
+                                                                u32x4* dst) {
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const Fp one = fe_one<FpP>();
+  Fp acc = one;
+  for (u32 j = 0; j < per; ++j) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) break;
+    st_fp_limbs(prefix + 4 * i, acc);
+    Fp zzz = ld_fp_limbs(scratch + 16 * i + 12);
+    u32 nz = 0;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) nz |= ld_fp_limbs(scratch + 16 * i + 8).l[k];
+    if (nz) acc = fe_mul<FpP>(acc, zzz);
+  }
+  // acc^(p-2)
+  Fp inv = one, base = acc;
+  {
+    constexpr u32 E[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                           0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    for (int w = 0; w < 12; ++w) {
+      for (int bit = 0; bit < 32; ++bit) {
+        if ((E[w] >> bit) & 1) inv = fe_mul<FpP>(inv, base);
+        base = fe_sqr<FpP>(base);
+      }
+    }
+  }
+  for (u32 j = per; j-- > 0;) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) continue;
+    Xyzz p = ld_xyzz(scratch, i);
+    u32x4* o = dst + 6 * i;
+    if (p.inf) {
+      const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[k] = z;
+      continue;
+    }
+    Fp zi = fe_mul<FpP>(inv, ld_fp_limbs(prefix + 4 * i));   // 1 / ZZZ_i
+    inv = fe_mul<FpP>(inv, p.zzz);
+    Fp t2 = fe_mul<FpP>(zi, p.zz);                            // ZZ / ZZZ
+    Fp zzi = fe_sqr<FpP>(t2);                                 // ZZ^2 / ZZZ^2 = 1 / ZZ
+    fe_store<FpP>(o, fe_mul<FpP>(p.x, zzi));
+    fe_store<FpP>(o + 3, fe_mul<FpP>(p.y, zi));
+  }
+}
+
 // ------------------------------------------------------------------ 1: digits
-__global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_form, MsmGeom g,
+__global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_form, MsmGeom g, u32 offset,
                                   u32* keys, u32* vals) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -106,8 +177,13 @@ __global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_for
     } else {
       carry = 0;
     }
-    keys[(size_t)k * n + i] = d ? ((k << g.bbits) | (d - 1)) : g.trash;
-    vals[(size_t)k * n + i] = (u32)i | (neg << 31);
+    if (g.nsets == 1) {  // table of 2^(c k) P: every window feeds the one bucket set
+      keys[(size_t)k * n + i] = d ? (d - 1) : g.trash;
+      vals[(size_t)k * n + i] = (k * g.row_stride + offset + (u32)i) | (neg << 31);
+    } else {
+      keys[(size_t)k * n + i] = d ? ((k << g.bbits) | (d - 1)) : g.trash;
+      vals[(size_t)k * n + i] = (offset + (u32)i) | (neg << 31);
+    }
   }
 }
 
@@ -117,7 +193,6 @@ struct AccArgs {
   const u32* vals;          // level 1: point index | sign << 31
   const u32x4* pts_in;      // level >= 2: XYZZ list
   const u32x4* bases;       // level 1: affine device-form bases (96 B each)
-  size_t base_offset;
   size_t len;               // entries at this level
   u32 chunk;                // entries per thread
   u32 offset;               // level >= 2: thread t covers [t*chunk - offset, (t+1)*chunk - offset)
@@ -202,7 +277,7 @@ __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs
         acc = xyzz_identity();
       }
       const u32 v = a.vals[e];
-      const u32x4* bp = a.bases + 6 * (a.base_offset + (size_t)(v & 0x7fffffffu));
+      const u32x4* bp = a.bases + 6 * (size_t)(v & 0x7fffffffu);
       Fp x = fe_load<FpP>(bp), y = fe_load<FpP>(bp + 3);
       u32 nz = 0;
 #pragma unroll
@@ -394,7 +469,9 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     return PM_OK;
   }
   if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
-  const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits);
+  if (bases->table_c && (size_t)bases->n * ((256 + bases->table_c - 1) / bases->table_c) > 0x7fffffffu)
+    return set_err(ctx, PM_ERR_BAD_ARG, "window table too large for 31-bit point indices");
+  const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n);
   const size_t m = n * g.nwin;  // (key, value) pairs
   // chunk sizes: level 1 reads L1 sorted pairs per thread; deeper levels read LN slots of the
   // (mostly empty) partial list, shifted by LN/2 so that the two slots a wave boundary leaves
@@ -403,7 +480,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   // mean run length n / 2^(c-1) -- a chunk shorter than the runs is a pass-through partial for the
   // latency-bound follow-up levels (2^22: 1.1 ms of them at 128, 0.2 ms at 256) -- at least 128,
   // and never so long that the grid drops below 2^17 threads.
-  const size_t avg_run = std::max<size_t>(1, n >> g.bbits);
+  const size_t avg_run = std::max<size_t>(1, m / ((size_t)g.nbuckets * g.nsets));
   const u32 L1 = ctx->opt_msm_chunk
                      ? (u32)ctx->opt_msm_chunk
                      : (u32)std::max<size_t>(16, std::min<size_t>(m >> 17, std::max<size_t>(128, 2 * avg_run)));
@@ -419,10 +496,10 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
       if (len <= 32) break;  // the next level is a single thread
     }
   }
-  const size_t total_buckets = (size_t)g.nbuckets * g.nwin;
+  const size_t total_buckets = (size_t)g.nbuckets * g.nsets;
   const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : 8u, g.nbuckets);
   const u32 chunks_per_win = g.nbuckets / LB;
-  const size_t total_chunks = (size_t)chunks_per_win * g.nwin;
+  const size_t total_chunks = (size_t)chunks_per_win * g.nsets;
 
   // workspace layout
   size_t sort_tmp = 0;
@@ -443,8 +520,8 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     o_ppts[i] = take(lens[i] * 256);
   }
   const size_t o_red = take(total_chunks * 256);
-  const size_t o_red2 = take((total_chunks / 256 + g.nwin) * 256);
-  const size_t o_win = take((size_t)g.nwin * 256);
+  const size_t o_red2 = take((total_chunks / 256 + g.nsets) * 256);
+  const size_t o_win = take((size_t)g.nsets * 256);
   int rc = ensure_buffer(ctx, ctx->msm_ws, off);
   if (rc) return rc;
   char* ws = (char*)ctx->msm_ws.ptr;
@@ -461,7 +538,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   {
   ProfScope prof(ctx, st, "msm_digits");
   hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                     (const u32x4*)d_scalars, n, scalar_form, g, keys0, vals0);
+                     (const u32x4*)d_scalars, n, scalar_form, g, (u32)offset, keys0, vals0);
   }
   PM_HIP(ctx, hipGetLastError());
   // 2 sort
@@ -474,8 +551,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   PM_HIP(ctx, hipMemsetAsync(buckets, 0, total_buckets * 256, st));
   AccArgs a;
   memset(&a, 0, sizeof a);
-  a.bases = (const u32x4*)bases->d_xy;
-  a.base_offset = offset;
+  a.bases = (const u32x4*)(bases->table_c ? bases->d_table : bases->d_xy);
   a.trash = g.trash;
   a.buckets = buckets;
   for (size_t lvl = 0; lvl < lens.size(); ++lvl) {
@@ -522,23 +598,24 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     const u32 per1 = std::min<u32>(256, chunks_per_win);
     const u32 groups = chunks_per_win / per1;  // per window
     if (groups > 1) {
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nwin * groups), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nsets * groups), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
                          (u32x4*)(ws + o_red2), 0u);
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red2), groups,
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nsets), dim3(64), 0, st, (const u32x4*)(ws + o_red2), groups,
                          (u32x4*)(ws + o_win), 1u);
     } else {
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nwin), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nsets), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
                          (u32x4*)(ws + o_win), 1u);
     }
   }
   PM_HIP(ctx, hipGetLastError());
   // 5 host fold
-  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)g.nwin * 256, hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)g.nsets * 256, hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
   const u32* hw = (const u32*)ctx->msm_host_pinned;
   XYZZ total = host::xyzz_identity();
-  for (u32 w = g.nwin; w-- > 0;) {
-    for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
+  for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no doublings at all
+    if (w + 1 < g.nsets)
+      for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
     total = host::xyzz_add(total, xyzz_to_host(hw + 64 * w));
   }
   write_projective(out_xyz, total);
@@ -591,9 +668,58 @@ extern "C" void pm_g1_bases_free(pm_ctx* ctx, pm_bases* bases) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (bases->d_xy) (void)hipFree(bases->d_xy);
+    if (bases->d_table) (void)hipFree(bases->d_table);
+    else if (bases->d_xy) (void)hipFree(bases->d_xy);
   }
   delete bases;
+}
+
+// Build the table of window multiples 2^(c w) * P_i (w < ceil(256 / c)) for a resident SRS.
+// Costs ~8 MSMs of time once and (ceil(256/c) - 1) x 96 n bytes of HBM; afterwards every MSM on
+// these bases uses ONE bucket set: no per-window bucket reduction, no doublings in the fold, and a
+// wider window (fewer additions per scalar).  window_bits 0 = the library's choice (20).
+extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t window_bits) {
+  if (!ctx || !bases) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (bases->table_c) return set_err(ctx, PM_ERR_BAD_ARG, "bases already carry a window table");
+  const u32 c = window_bits ? window_bits : 20u;
+  if (c < 8 || c > 22) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..22");
+  const size_t n = bases->n;
+  if (n == 0) return PM_OK;
+  const u32 nwin = (256 + c - 1) / c;
+  if (n * nwin > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "n * windows exceeds 2^31 table entries");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  void* table = nullptr;
+  PM_HIP(ctx, hipMalloc(&table, n * nwin * 96));
+  int rc = ensure_buffer(ctx, ctx->msm_ws, n * (256 + 64));
+  if (rc) {
+    (void)hipFree(table);
+    return rc;
+  }
+  u32x4* scratch = (u32x4*)ctx->msm_ws.ptr;
+  u32x4* prefix = scratch + 16 * n;
+  hipError_t e = hipMemcpyAsync(table, bases->d_xy, n * 96, hipMemcpyDeviceToDevice, st);
+  const size_t want = std::max<size_t>((n + 63) / 64, std::min<size_t>(n, (size_t)ctx->num_cus * 512));
+  const unsigned blocks = (unsigned)((want + 127) / 128);
+  const u32 per = (u32)((n + (size_t)blocks * 128 - 1) / ((size_t)blocks * 128));
+  for (u32 w = 1; w < nwin && e == hipSuccess; ++w) {
+    const u32x4* src = (const u32x4*)table + 6 * n * (w - 1);
+    u32x4* dst = (u32x4*)table + 6 * n * w;
+    hipLaunchKernelGGL(precompute_double_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, src, n, c, scratch);
+    hipLaunchKernelGGL(precompute_affine_kernel, dim3(blocks), dim3(128), 0, st, (const u32x4*)scratch, n, per, prefix, dst);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)hipFree(table);
+    return set_err(ctx, PM_ERR_HIP, std::string("bases precompute: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(bases->d_xy);
+  bases->d_xy = table;  // row 0 == the bases themselves
+  bases->d_table = table;
+  bases->table_c = c;
+  return PM_OK;
 }
 
 extern "C" size_t pm_g1_bases_len(const pm_bases* bases) { return bases ? bases->n : 0; }

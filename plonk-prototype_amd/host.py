@@ -320,6 +320,11 @@ class Bases:
         ctx._check(ctx._lib.pm_g1_bases_upload(ctx._h, _p(src), self.n, C.byref(h)))
         self._h = h
 
+    def precompute(self, window_bits: int = 0):
+        """Build the resident table of window multiples (``pm_g1_bases_precompute``)."""
+        self.ctx._check(self.ctx._lib.pm_g1_bases_precompute(self.ctx._h, self._h, window_bits))
+        return self
+
     def free(self):
         if getattr(self, "_h", None) and self.ctx._h:
             self.ctx._lib.pm_g1_bases_free(self.ctx._h, self._h)
@@ -389,9 +394,11 @@ class CommitKey:
     """``dusk_plonk::commitment_scheme::kzg10::CommitKey``: holds ``powers_of_g`` on the device;
     ``commit`` checks the degree (PolynomialDegreeTooLarge) and runs one MSM."""
 
-    def __init__(self, powers_of_g, ctx: Context | None = None):
+    def __init__(self, powers_of_g, ctx: Context | None = None, precompute: bool = False):
         self.ctx = ctx or default_context()
         self._bases = Bases(self.ctx, powers_of_g)
+        if precompute:      # a long-lived SRS: trade HBM for ~20 % faster commits
+            self._bases.precompute()
 
     def max_degree(self) -> int:
         return self._bases.n - 1

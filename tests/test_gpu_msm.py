@@ -121,6 +121,31 @@ def test_commit_key_mirror(ctx, oracle):
         pa.msm_variable_base(pts, poly, ctx)                           # length mismatch
 
 
+@pytest.mark.parametrize("c", [0, 8, 13, 16])
+def test_precomputed_window_table(ctx, oracle, c):
+    """pm_g1_bases_precompute: same result from the one-bucket-set path, for every table width,
+    for prefixes of the SRS (commit of a shorter polynomial) and for offset shards."""
+    import plonk_prototype_amd as pa
+    import torch
+    n = 5000
+    pts, sc = _edge_inputs(oracle, n, 77)
+    bases = pa.host.Bases(ctx, pts).precompute(c)
+    for m in (n, 1234, 1, 0):
+        got, _ = pa.g1_to_affine(bases.msm(sc[:m]))
+        assert np.array_equal(got, oracle.g1_msm(pts[:m], sc[:m], SCALAR_MONTGOMERY, 8)), (c, m)
+    canon = oracle.fr_from_mont(sc)
+    got, _ = pa.g1_to_affine(bases.msm(canon, SCALAR_CANONICAL))
+    assert np.array_equal(got, oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 8))
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    part = bases.msm_dev(d_sc.data_ptr() + 32 * 1000, 3000, offset=1000)
+    assert np.array_equal(pa.g1_to_affine(part)[0], oracle.g1_msm(pts[1000:4000], sc[1000:4000], SCALAR_MONTGOMERY, 8))
+    with pytest.raises(pa.Error):
+        bases.precompute(c)                                           # only once
+    # skewed digits through the table path
+    eq = np.repeat(oracle.fr_sample(7, 1), n, axis=0)
+    assert np.array_equal(pa.g1_to_affine(bases.msm(eq))[0], oracle.g1_msm(pts, eq, SCALAR_MONTGOMERY, 8))
+
+
 def test_sharded_msm_fold(ctx, oracle):
     """The multi-GPU decomposition on one GPU: shard by points, fold the partials."""
     import plonk_prototype_amd as pa
@@ -151,6 +176,8 @@ def test_full_size_2_20(ctx, oracle):
     dl = oracle.expected_dlog(sc, SCALAR_MONTGOMERY, K0, DD)
     assert np.array_equal(got, oracle.g1_mul(oracle.g1_generator(), dl))
     assert np.array_equal(got, oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 16))
+    ck_table = pa.CommitKey(pts, ctx, precompute=True)               # resident-SRS table path
+    assert np.array_equal(ck_table.commit(sc), got)
     # witness-like distribution: 90 % below 2^16, 5 % zero, 1 % one
     vals = limbs_to_ints(oracle.fr_from_mont(sc[: 1 << 16]))
     w = []
