@@ -109,6 +109,7 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   for (int d = 0; d < 2; ++d) {
     for (auto& kv : ctx->step_tw[d]) hipFree(kv.second);
+    for (auto& kv : ctx->step4_tw[d]) hipFree(kv.second);
     for (auto& kv : ctx->domain[d]) {
       hipFree(kv.second.tw_hi);
       hipFree(kv.second.tw_lo);
@@ -181,13 +182,18 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_msm_lb = value;
     return PM_OK;
   }
+  if (!strcmp(key, "ntt_radix")) {
+    if (value != 4 && value != 8) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_radix must be 4 or 8");
+    ctx->opt_ntt_radix = value;
+    return PM_OK;
+  }
   if (!strcmp(key, "ntt_max_radix")) {
     if (value < 6 || value > 10) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_max_radix must be 6..10");
     ctx->opt_ntt_max_radix = value;
     return PM_OK;
   }
   if (!strcmp(key, "ntt_tile_log")) {
-    if (value != 0 && value != 11 && value != 12) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_tile_log must be 0 (auto), 11 or 12");
+    if (value != 0 && (value < 10 || value > 12)) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_tile_log must be 0 (auto), 10, 11 or 12");
     ctx->opt_ntt_tile_log = value;
     return PM_OK;
   }

@@ -35,6 +35,7 @@ struct pm_ctx {
   std::string err;
   // NTT caches
   std::map<unsigned, void*> step_tw[2];                 // [dir][S] -> device table
+  std::map<unsigned, void*> step4_tw[2];                // same for the radix-4 kernels
   std::map<unsigned, pm::NttDomainTables> domain[2];    // [dir][log_n]
   pm::DeviceBuffer ntt_tmp[2];
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
@@ -60,6 +61,7 @@ struct pm_ctx {
   // tunables
   long opt_msm_window_bits = 0;  // 0 = auto
   long opt_ntt_tile_log = 0;     // 0 = auto
+  long opt_ntt_radix = 4;        // in-tile butterfly radix: 4 (4 elements per thread) or 8
   long opt_ntt_max_radix = 10;   // log2 of the largest pass radix (multi-pass plans)
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)

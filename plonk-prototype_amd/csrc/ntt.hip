@@ -24,7 +24,8 @@ struct PassEntry {
 };
 // (S, LT): LT = 0 single-pass kernels; multi-pass tiles of 2^11 (LT = 11 - S) or 2^12 elements
 #define PM_SINGLE(X) X(3, 0) X(4, 0) X(5, 0) X(6, 0) X(7, 0) X(8, 0) X(9, 0) X(10, 0)
-#define PM_MULTI(X) X(5, 6) X(6, 5) X(7, 4) X(8, 3) X(9, 2) X(10, 1) X(8, 4) X(9, 3) X(10, 2)
+#define PM_MULTI(X) \
+  X(5, 6) X(6, 5) X(7, 4) X(8, 3) X(9, 2) X(10, 1) X(8, 4) X(9, 3) X(10, 2) X(5, 5) X(6, 4) X(7, 3) X(8, 2)
 static const PassEntry kPassTable[] = {
 #define X(S, LT) {S, LT, ROLE_SINGLE, ntt_pass_kernel<S, LT, false, false, false>},
     PM_SINGLE(X)
@@ -41,6 +42,12 @@ static pass_fn find_pass(int S, int LT, int role) {
     if (e.S == S && e.LT == LT && e.role == role) return e.fn;
   return nullptr;
 }
+
+// radix-4 kernels (ntt4.hip)
+pass_fn find_pass4(int S, int LT, int role);
+size_t pass4_lds(int S, int LT);
+unsigned pass4_threads(int S, int LT);
+int build_step4_table(pm_ctx* ctx, void** out, const NttConsts& c, unsigned S, hipStream_t st);
 
 struct Plan {
   int npass = 0;
@@ -59,10 +66,13 @@ static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10) {
   int base = (int)log_n / p.npass, extra = (int)log_n % p.npass;
   for (int i = 0; i < p.npass; ++i) {
     p.S[i] = base + (i < extra ? 1 : 0);
-    // tile_log 0 = auto: 2^11-element tiles, but never fewer than 4 adjacent columns (runs of
-    // 64 B per limb plane): measured at 2^20, T = 2 -> 4 takes the last pass from 84 to 73 us
-    int lt = tile_log ? tile_log - p.S[i] : std::max(11 - p.S[i], 2);
-    if (p.S[i] < 8) lt = 11 - p.S[i];  // 2^12-element tiles exist for S >= 8 only
+    // tile_log 0 = auto (measured, profiles/r01_ntt_sweep.txt): 2^10-element tiles for S <= 8 (four
+    // or more independent workgroups per CU, so barrier phases of one overlap arithmetic of
+    // another), never fewer than 4 adjacent columns (64-byte runs per limb group)
+    int lt = tile_log ? tile_log - p.S[i] : std::max(10 - p.S[i], 2);
+    if (p.S[i] < 8 && lt > 11 - p.S[i]) lt = 11 - p.S[i];  // 2^12-element tiles exist for S >= 8 only
+    if (lt < 1) lt = 1;
+    if (tile_log == 10 && p.S[i] > 8) lt = 11 - p.S[i];     // 2^10-element tiles exist for S <= 8 only
     lt = std::min(lt, (int)log_n - p.S[i]);
     p.LT[i] = lt;
   }
@@ -118,6 +128,26 @@ static int get_step_table(pm_ctx* ctx, int dir, unsigned S, void** out, hipStrea
   hipLaunchKernelGGL(step_tw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (u32x4*)d, c, S);
   PM_HIP(ctx, hipGetLastError());
   ctx->step_tw[dir][S] = d;
+  *out = d;
+  return PM_OK;
+}
+
+static int get_step4_table(pm_ctx* ctx, int dir, unsigned S, void** out, hipStream_t st) {
+  auto it = ctx->step4_tw[dir].find(S);
+  if (it != ctx->step4_tw[dir].end()) {
+    *out = it->second;
+    return PM_OK;
+  }
+  HFr wR = domain_gen(S);
+  if (dir) wR = host::inv(wR, host::FR());
+  NttConsts c;
+  memset(&c, 0, sizeof c);
+  to_limbs(c.w8[0], wR);
+  to_limbs(c.one, host::one(host::FR()));
+  void* d = nullptr;
+  int rc = build_step4_table(ctx, &d, c, S, st);
+  if (rc) return rc;
+  ctx->step4_tw[dir][S] = d;
   *out = d;
   return PM_OK;
 }
@@ -249,10 +279,11 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     // in-place transform needs a canonical bounce buffer (ntt_tmp[0]) plus a copy
     void* dst = (last && !(plan.npass == 1 && inplace)) ? d_out : ctx->ntt_tmp[i & 1].ptr;
     const int role = plan.npass == 1 ? ROLE_SINGLE : (i == 0 ? ROLE_FIRST : (last ? ROLE_LAST : ROLE_MIDDLE));
-    pass_fn fn = find_pass(S, LT, role);
+    const bool r4 = ctx->opt_ntt_radix == 4 && find_pass4(S, LT, role) != nullptr;
+    pass_fn fn = r4 ? find_pass4(S, LT, role) : find_pass(S, LT, role);
     if (!fn) return set_err(ctx, PM_ERR_BAD_ARG, "no kernel for this pass shape");
     void* stw = nullptr;
-    rc = get_step_table(ctx, dir, (unsigned)S, &stw, st);
+    rc = r4 ? get_step4_table(ctx, dir, (unsigned)S, &stw, st) : get_step_table(ctx, dir, (unsigned)S, &stw, st);
     if (rc) return rc;
     a.in = src;
     a.out = dst;
@@ -284,8 +315,8 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
       tw_flag = PASS_DIRECT_TW;
     }
     a.flags = (i == 0 ? pre : 0u) | post_i | tw_flag;
-    const unsigned threads = std::max(64u, (1u << (S + LT)) / 8);
-    const size_t lds = pass_lds_bytes(S, LT);
+    const unsigned threads = r4 ? pass4_threads(S, LT) : std::max(64u, (1u << (S + LT)) / 8);
+    const size_t lds = r4 ? pass4_lds(S, LT) : pass_lds_bytes(S, LT);
     if (lds > 64 * 1024)
       PM_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));

@@ -34,19 +34,34 @@ def test_every_plan_against_oracle(ctx, oracle, k):
             assert np.array_equal(ctx.fr_ntt(a[:in_len], k, flags), oracle.fr_ntt(a[:in_len], k, flags, 8))
 
 
+@pytest.mark.parametrize("radix", [4, 8])
 @pytest.mark.parametrize("k,tile,maxr", [(12, 12, 10), (16, 11, 10), (16, 12, 8), (20, 11, 10), (20, 12, 10),
-                                           (20, 11, 7), (18, 11, 6), (21, 12, 9)])
-def test_plan_options(ctx, oracle, k, tile, maxr):
-    """Every tile shape / pass split the tunables can select gives the same bits."""
+                                           (20, 11, 7), (18, 11, 6), (21, 12, 9), (20, 10, 8), (19, 10, 7)])
+def test_plan_options(ctx, oracle, k, tile, maxr, radix):
+    """Every kernel family / tile shape / pass split the tunables can select gives the same bits."""
     a = oracle.fr_sample(12 + k, 1 << k)
     ctx.set_option("ntt_tile_log", tile)
     ctx.set_option("ntt_max_radix", maxr)
+    ctx.set_option("ntt_radix", radix)
     try:
         for flags in ALL_FLAGS:
             assert np.array_equal(ctx.fr_ntt(a, k, flags), oracle.fr_ntt(a, k, flags, 8))
     finally:
         ctx.set_option("ntt_tile_log", 0)
         ctx.set_option("ntt_max_radix", 10)
+        ctx.set_option("ntt_radix", 4)
+
+
+@pytest.mark.parametrize("k", [3, 4, 7, 9, 10, 11, 13, 14, 17])
+def test_radix8_family(ctx, oracle, k):
+    """The radix-8 kernels (non-default) over single- and multi-pass sizes."""
+    a = oracle.fr_sample(99 + k, (1 << k) - (1 << k) // 3)
+    ctx.set_option("ntt_radix", 8)
+    try:
+        for flags in ALL_FLAGS:
+            assert np.array_equal(ctx.fr_ntt(a, k, flags), oracle.fr_ntt(a, k, flags, 8))
+    finally:
+        ctx.set_option("ntt_radix", 4)
 
 
 @pytest.mark.parametrize("k", [2, 7, 10, 13, 20])

@@ -5,10 +5,11 @@ import numpy as np, torch
 import plonk_prototype_amd as pa
 ctx = pa.Context(0)
 st = torch.cuda.current_stream().cuda_stream
-def run(k, batch, flags, tile, reps=10, maxr=10):
+def run(k, batch, flags, tile, reps=10, maxr=10, radix=8):
     n = 1 << k
     ctx.set_option("ntt_tile_log", tile)
     ctx.set_option("ntt_max_radix", maxr)
+    ctx.set_option("ntt_radix", radix)
     a = torch.randint(0, 2**31, (batch * n * 4,), dtype=torch.int64, device="cuda")  # not canonical; timing only
     a &= (1 << 60) - 1
     b = torch.empty_like(a)
@@ -24,8 +25,21 @@ def run(k, batch, flags, tile, reps=10, maxr=10):
     prof = ctx.profile_read(); ctx.profile(False)
     ks = {s: round(v[1] / v[0] * 1e3, 1) for s, v in prof.items()}
     bf = batch * (n // 2) * k / dt
-    print(f"k={k} batch={batch} flags={flags} tile={tile} maxr={maxr}: {dt*1e6:8.1f} us/call  {bf:.3e} butterflies/s  kernels_us={ks}", flush=True)
-for k in (16, 18, 20, 21, 22, 24):
-    for maxr in (10, 9, 8, 7, 6):
-        run(k, 1, 0, 11, maxr=maxr)
-run(20, 1, 0, 12, maxr=10); run(20, 4, 0, 11, maxr=7); run(20, 4, 0, 12, maxr=10)
+    print(f"k={k} batch={batch} flags={flags} tile={tile} maxr={maxr} radix={radix}: {dt*1e6:8.1f} us/call  {bf:.3e} butterflies/s  kernels_us={ks}", flush=True)
+import sys
+from oracle.cpu_oracle import CpuOracle
+o = CpuOracle()
+# correctness of the radix-4 kernels first
+for k in (3, 4, 5, 8, 9, 10, 11, 12, 13, 16, 20):
+    a = o.fr_sample(k, 1 << k)
+    ctx.set_option("ntt_radix", 4)
+    for maxr in (10, 7):
+        ctx.set_option("ntt_max_radix", maxr)
+        for flags in (0, 1, 2, 3):
+            ok = np.array_equal(ctx.fr_ntt(a, k, flags), o.fr_ntt(a, k, flags, 8))
+            if not ok: print("RADIX4 MISMATCH", k, maxr, flags, flush=True)
+print("radix-4 check done", flush=True)
+for k in (20, 22, 24):
+    for radix in (8, 4):
+        for maxr, tile in ((10, 0), (8, 11), (8, 10), (7, 10)):
+            run(k, 1, 0, tile, maxr=maxr, radix=radix)
