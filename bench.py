@@ -110,14 +110,20 @@ def main():
     s_dom = passes[0] if dom.endswith("first") or dom.endswith("single") else passes[-1]
     algo_bytes = 64 * n * s_dom / k                                # 64 N bytes per transform, S/k of it per pass
     achieved = algo_bytes / (dom_ms * 1e-3)
-    traffic = None
+    traffic = valu = None
     tpath = os.path.join(ROOT, "profiles", "ntt_traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(f"{dom}_2^{k}")
+        pmc = json.load(open(tpath))
+        traffic = pmc.get(f"{dom}_2^{k}")
+        insts = pmc.get(f"{dom}_2^{k}_valu_insts")
+        if insts:   # the bound that actually binds: VALU wave-instructions (PMC) at 1 per 4 cycles per SIMD
+            simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+            valu = {"wave_insts_per_launch": insts, "peak_issue": "1 wave-instruction / 4 cycles / SIMD at 2.4 GHz",
+                    "util": round(insts * 4 / (dom_ms * 1e-3 * 2.4e9 * simds), 3)}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                 "avg_launch_us": round(dom_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(algo_bytes),
-                "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()},
+                "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()}, "valu": valu,
                 "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
 
     # ------------------------------------------------------------------ MSM legs

@@ -29,12 +29,16 @@ roles = {("true", "false", "true"): "ntt_pass_first", ("false", "true", "true"):
          ("false", "true", "false"): "ntt_pass_last", ("false", "false", "false"): "ntt_pass_single"}
 log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 for k, v in summary.items():
-    m = re.match(r"pm::ntt_pass_kernel<(\d+), (\d+), (\w+), (\w+), (\w+)>", k)
+    m = re.match(r"pm::ntt_pass4?_kernel<(\d+), (\d+), (\w+), (\w+), (\w+)>", k)
     if m and "hbm_bytes_per_launch_corrected" in v:
         traffic[f"{roles[(m.group(3), m.group(4), m.group(5))]}_2^{log_n}"] = int(v["hbm_bytes_per_launch_corrected"])
+        if "SQ_INSTS_VALU" in v:
+            traffic[f"{roles[(m.group(3), m.group(4), m.group(5))]}_2^{log_n}_valu_insts"] = int(v["SQ_INSTS_VALU"]["mean"])
 for k, v in summary.items():
     if k.startswith("pm::msm_accumulate_l1") and "hbm_bytes_per_launch_corrected" in v:
         traffic[f"msm_accumulate_l1_2^{log_n}"] = int(v["hbm_bytes_per_launch_corrected"])
+        if "SQ_INSTS_VALU" in v:
+            traffic[f"msm_accumulate_l1_2^{log_n}_valu_insts"] = int(v["SQ_INSTS_VALU"]["mean"])
 if traffic:
     json.dump(traffic, open(os.path.join(os.path.dirname(out), "ntt_traffic.json"), "w"), indent=1, sort_keys=True)
     print("traffic:", traffic)
