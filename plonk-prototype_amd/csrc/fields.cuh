@@ -331,10 +331,6 @@ template <class P>
 PM_DEV Fe<P> fe_abi_to_dev(const Fe<P>& a) {  // multiply by 2^(WN - 32NS): fe_mul by 2^(2WN - 32NS)
   return fe_mul<P>(a, fe_pow2<P, 2 * P::W * P::N - 32 * P::NS>());
 }
-template <class P>
-PM_DEV Fe<P> fe_dev_to_abi(const Fe<P>& a) {  // multiply by 2^(32NS - WN): fe_mul by 2^(32NS)
-  return fe_mul<P>(a, fe_pow2<P, 32 * P::NS>());
-}
 
 // ------------------------------------------------------------------ canonical boundary
 // saturated canonical (NS x 32 bit) -> radix 2^W, normalised
@@ -396,22 +392,6 @@ PM_DEV void fe_canon_pack(u32* s, const Fe<P>& a) {
 #pragma unroll
   for (int i = 0; i < N; ++i) x.l[i] = neg ? x.l[i] : d.l[i];
   fe_pack_raw<P>(s, x);
-}
-
-template <class P>
-PM_DEV Fe<P> fe_const_sat(const u32* s) {  // uniform saturated constant -> limbs
-  return fe_unpack<P>(s);
-}
-
-// exact zero test for a value known to be < 2m with any limb slack: canonicalise first
-template <class P>
-PM_DEV bool fe_is_zero_canon(const Fe<P>& a) {
-  u32 s[P::NS];
-  fe_canon_pack<P>(s, a);
-  u32 x = 0;
-#pragma unroll
-  for (int i = 0; i < P::NS; ++i) x |= s[i];
-  return x == 0;
 }
 
 // ------------------------------------------------------------------ 16-byte vector IO

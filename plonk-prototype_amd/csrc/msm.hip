@@ -476,14 +476,14 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   // chunk sizes: level 1 reads L1 sorted pairs per thread; deeper levels read LN slots of the
   // (mostly empty) partial list, shifted by LN/2 so that the two slots a wave boundary leaves
   // behind (tail of lane 63, head of the next lane 0) fall into the same chunk
-  // Entries per thread in the big kernel (measured, profiles/r01_msm_sweep.txt): at least twice the
-  // mean run length n / 2^(c-1) -- a chunk shorter than the runs is a pass-through partial for the
-  // latency-bound follow-up levels (2^22: 1.1 ms of them at 128, 0.2 ms at 256) -- at least 128,
-  // and never so long that the grid drops below 2^17 threads.
+  // Entries per thread in the big kernel (measured, profiles/r01_msm_sweep.txt): at least four times
+  // the mean run length m / #buckets -- a chunk not much longer than the runs leaves pass-through
+  // partials for the latency-bound follow-up levels (0.2 ms of them at a ratio of 4.7, 0.75 ms at
+  // 2.5) -- at least 128, and never so long that the grid drops below 2^17 threads.
   const size_t avg_run = std::max<size_t>(1, m / ((size_t)g.nbuckets * g.nsets));
   const u32 L1 = ctx->opt_msm_chunk
                      ? (u32)ctx->opt_msm_chunk
-                     : (u32)std::max<size_t>(16, std::min<size_t>(m >> 17, std::max<size_t>(128, 2 * avg_run)));
+                     : (u32)std::max<size_t>(16, std::min<size_t>(m >> 17, std::max<size_t>(128, 4 * avg_run)));
   const u32 LN = 8, LN_OFF = 4;
   std::vector<size_t> lens;  // lens[0] = m (level 1 input), lens[i] = partial list length
   lens.push_back(m);

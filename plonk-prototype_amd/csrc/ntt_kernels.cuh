@@ -192,8 +192,6 @@ PM_DEV void dft4(Fr& a0, Fr& a1, Fr& a2, Fr& a3, const Fr& w4) {
   a2 = t;
 }
 
-__host__ __device__ constexpr int bitrev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
-
 // Offsets (in entries) of each in-tile step's twiddle block inside step_tw for radix 2^S:
 // step s has sub-size Ns' = 8^s and radix q; block = (q-1) * Ns' entries laid out [t-1][k'].
 __host__ __device__ constexpr int step_radix_log(int S, int s) { return (S - 3 * s) >= 3 ? 3 : (S - 3 * s); }

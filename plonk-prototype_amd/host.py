@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import u64p, u32p
+from ._lib import u64p
 
 
 class Error(Exception):

@@ -1,0 +1,30 @@
+"""GPU sweep (not a test): MSM with the resident-SRS table, window width x bucket chunk."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import plonk_prototype_amd as pa
+from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+o = CpuOracle()
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = 1 << k
+ctx = pa.Context(0)
+pts = o.g1_bases_arith(ints_to_limbs([0x1234567], 4)[0], ints_to_limbs([0xabcdef123456789abcdef], 4)[0], n, 16)
+sc = o.fr_sample(0x5343414C, n)
+d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+ref = None
+for c in (17, 18, 19, 20, 21):
+    bases = pa.host.Bases(ctx, pts).precompute(c)
+    for lb in (4, 8, 16, 32):
+        ctx.set_option("msm_lb", lb)
+        r = bases.msm_dev(d_sc.data_ptr(), n)
+        if ref is None: ref = r
+        assert np.array_equal(r, ref)
+        ctx.sync(); ctx.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(3): bases.msm_dev(d_sc.data_ptr(), n)
+        dt = (time.perf_counter() - t0) / 3
+        prof = ctx.profile_read(); ctx.profile(False)
+        ks = {s.replace("msm_", ""): round(v[1] / 3 * 1e3) for s, v in prof.items()}
+        print(f"c={c} lb={lb:2d} {dt*1e3:7.3f} ms  {ks}", flush=True)
+    ctx.set_option("msm_lb", 0)
+    bases.free()
