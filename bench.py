@@ -51,10 +51,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # Rehearsal knobs (not used by the driver): PM_BENCH_DEVICE pins every rank to one GPU and
+    # PM_BENCH_BACKEND=gloo moves the 144-byte collectives to the CPU, so the multi-rank code path
+    # can be exercised on a one-GPU box.
+    backend = os.environ.get("PM_BENCH_BACKEND", "nccl")
+    if "PM_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PM_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         ctx.sync()                       # the library's own stream
@@ -65,7 +75,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -147,7 +157,7 @@ def main():
 
         def msm_step():
             part = bases.msm_dev(d_sc.data_ptr(), hi - lo, stream=stream)
-            return allgather_fold(part, dev if world > 1 else None)
+            return allgather_fold(part, coll_dev if world > 1 else None)
 
         res = msm_step()
         barrier()

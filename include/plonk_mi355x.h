@@ -114,7 +114,7 @@ int pm_fr_ntt_dev(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride
 int pm_g1_bases_upload(pm_ctx* ctx, const uint64_t* xy, size_t n, pm_bases** out);
 /* Optional, for a long-lived SRS: build the table of window multiples 2^(c w) * bases[i] in HBM
  * ((ceil(256/c) - 1) x 96 n extra bytes; about 8 MSMs of time, once).  Every later MSM on these
- * bases then needs one bucket set and no doublings: ~20 % faster.  window_bits 0 = default (20). */
+ * bases then needs one bucket set and no doublings: ~15 % faster.  window_bits 0 = default (log2 n, at most 20). */
 int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t window_bits);
 void pm_g1_bases_free(pm_ctx* ctx, pm_bases* bases);
 size_t pm_g1_bases_len(const pm_bases* bases);

@@ -677,14 +677,17 @@ extern "C" void pm_g1_bases_free(pm_ctx* ctx, pm_bases* bases) {
 // Build the table of window multiples 2^(c w) * P_i (w < ceil(256 / c)) for a resident SRS.
 // Costs ~8 MSMs of time once and (ceil(256/c) - 1) x 96 n bytes of HBM; afterwards every MSM on
 // these bases uses ONE bucket set: no per-window bucket reduction, no doublings in the fold, and a
-// wider window (fewer additions per scalar).  window_bits 0 = the library's choice (20).
+// wider window (fewer additions per scalar).  window_bits 0 = the library's choice (log2 n, <= 20).
 extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t window_bits) {
   if (!ctx || !bases) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (bases->table_c) return set_err(ctx, PM_ERR_BAD_ARG, "bases already carry a window table");
-  const u32 c = window_bits ? window_bits : 20u;
-  if (c < 8 || c > 22) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..22");
   const size_t n = bases->n;
+  u32 lg = 0;
+  while (((size_t)2 << lg) <= std::max<size_t>(n, 1)) ++lg;
+  // default: about one bucket per point (measured best at 2^20: c = 20), at most 2^19 buckets
+  const u32 c = window_bits ? window_bits : std::min<u32>(20u, std::max<u32>(12u, lg));
+  if (c < 8 || c > 22) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..22");
   if (n == 0) return PM_OK;
   const u32 nwin = (256 + c - 1) / c;
   if (n * nwin > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "n * windows exceeds 2^31 table entries");
