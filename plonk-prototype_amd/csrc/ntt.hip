@@ -63,6 +63,7 @@ static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10) {
     return p;
   }
   p.npass = (int)((log_n + max_radix - 1) / max_radix);
+  p.npass = std::min(p.npass, (int)log_n / 5);  // multi-pass kernels exist for radix >= 2^5
   int base = (int)log_n / p.npass, extra = (int)log_n % p.npass;
   for (int i = 0; i < p.npass; ++i) {
     p.S[i] = base + (i < extra ? 1 : 0);

@@ -461,7 +461,9 @@ extern "C" int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, voi
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   // enough threads to fill the chip, at most 64 elements per thread
-  const size_t want_threads = std::max<size_t>((n + 63) / 64, std::min<size_t>(n, (size_t)ctx->num_cus * 1024));
+  // one Fermat inversion (~380 products) per thread: 64 elements per thread amortise it to ~6
+  // products per element; below 2^22 elements keep at least one wave per SIMD instead
+  const size_t want_threads = std::max<size_t>((n + 63) / 64, std::min<size_t>(n, (size_t)ctx->num_cus * 256));
   const unsigned blocks = (unsigned)((want_threads + 255) / 256);
   const size_t T = (size_t)blocks * 256;
   const u32 L = (u32)((n + T - 1) / T);

@@ -1,0 +1,114 @@
+"""Seeded random sweeps of the ABI against the oracle: shapes, flags, tunables and scalar/base
+structure nobody hand-picked.  Deterministic (fixed seeds), a few seconds on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as B
+from oracle.cpu_oracle import COSET, INVERSE, SCALAR_CANONICAL, SCALAR_MONTGOMERY, ints_to_limbs, limbs_to_ints
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ntt_random_shapes(ctx, oracle):
+    rng = np.random.default_rng(20261003)
+    for case in range(80):
+        k = int(rng.integers(0, 15))
+        n = 1 << k
+        in_len = int(rng.integers(0, n + 1))
+        flags = int(rng.integers(0, 4))
+        a = oracle.fr_sample(1000 + case, n)[:in_len]
+        if in_len and rng.random() < 0.3:                      # sparse / structured inputs
+            a[rng.integers(0, in_len, size=max(1, in_len // 2))] = 0
+        ctx.set_option("ntt_radix", int(rng.choice([4, 8])))
+        ctx.set_option("ntt_max_radix", int(rng.integers(6, 11)))
+        try:
+            got = ctx.fr_ntt(a, k, flags)
+        finally:
+            ctx.set_option("ntt_radix", 4)
+            ctx.set_option("ntt_max_radix", 10)
+        assert np.array_equal(got, oracle.fr_ntt(a, k, flags, 4)), (case, k, in_len, flags)
+
+
+def test_ntt_extreme_values(ctx, oracle):
+    """Inputs at the edges of the canonical range (0, 1, r-1, r-2, 2^255 mod r, ...) in every slot."""
+    k, n = 11, 1 << 11
+    edge = [0, 1, 2, B.R_MOD - 1, B.R_MOD - 2, (1 << 255) % B.R_MOD, (1 << 254), B.R_MOD // 2, B.R_MOD // 2 + 1]
+    vals = [edge[(i * 7 + i // 5) % len(edge)] for i in range(n)]
+    a = oracle.fr_to_mont(ints_to_limbs(vals, 4))
+    raw = ints_to_limbs(vals, 4)                               # the same limbs read as Montgomery data
+    for x in (a, raw):
+        for flags in (0, INVERSE, COSET, INVERSE | COSET):
+            assert np.array_equal(ctx.fr_ntt(x, k, flags), oracle.fr_ntt(x, k, flags, 4))
+    top = oracle.fr_to_mont(ints_to_limbs([B.R_MOD - 1] * n, 4))   # every element r-1
+    assert np.array_equal(ctx.fr_ntt(top, k, 0), oracle.fr_ntt(top, k, 0, 4))
+
+
+def test_msm_random_structure(ctx, oracle):
+    import plonk_prototype_amd as pa
+    rng = np.random.default_rng(777)
+    k0 = ints_to_limbs([0x77777], 4)[0]
+    dd = ints_to_limbs([0x123456789abcdef0123], 4)[0]
+    pool = oracle.g1_bases_arith(k0, dd, 4096, 8)
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+    for case in range(40):
+        n = int(rng.integers(1, 3500))
+        pts = pool[rng.integers(0, 4096 if rng.random() < 0.6 else 8, size=n)].copy()   # many duplicates sometimes
+        sc = oracle.fr_sample(5000 + case, n)
+        mode = case % 5
+        if mode == 1:
+            sc[rng.random(n) < 0.5] = 0
+            sc[rng.random(n) < 0.3] = one
+        elif mode == 2:
+            small = [int(v) for v in rng.integers(0, 1 << 16, size=n)]
+            sc = oracle.fr_to_mont(ints_to_limbs(small, 4))
+        elif mode == 3:
+            sc[:] = sc[0]
+        elif mode == 4:                                        # negated copies and points at infinity
+            neg = pts.copy()
+            ys = limbs_to_ints(oracle.fp_from_mont(np.ascontiguousarray(pts[:, 6:])))
+            neg[:, 6:] = oracle.fp_to_mont(ints_to_limbs([(B.P_MOD - y) % B.P_MOD for y in ys], 6))
+            flip = rng.random(n) < 0.4
+            pts[flip] = neg[flip]
+            pts[rng.random(n) < 0.1] = 0
+        exp = oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 8)
+        c = int(rng.choice([0, 6, 9, 12, 15]))
+        ctx.set_option("msm_window_bits", c)
+        ctx.set_option("msm_chunk", int(rng.choice([0, 16, 32, 64])))
+        try:
+            bases = pa.host.Bases(ctx, pts)
+            got, _ = pa.g1_to_affine(bases.msm(sc))
+            assert np.array_equal(got, exp), (case, n, mode, c)
+            if case % 3 == 0:
+                bases.precompute(int(rng.choice([0, 9, 14])))
+                got, _ = pa.g1_to_affine(bases.msm(oracle.fr_from_mont(sc), SCALAR_CANONICAL))
+                assert np.array_equal(got, exp), (case, n, mode, "table")
+            bases.free()
+        finally:
+            ctx.set_option("msm_window_bits", 0)
+            ctx.set_option("msm_chunk", 0)
+
+
+def test_field_limb_patterns(ctx, oracle):
+    """Saturated limb patterns (all-ones words, alternating words) that stress the 29/28-bit re-limbing."""
+    pats = []
+    for mod, nl in ((B.R_MOD, 4), (B.P_MOD, 6)):
+        words = [0xFFFFFFFFFFFFFFFF, 0, 0xAAAAAAAAAAAAAAAA, 0x5555555555555555, 0x00000000FFFFFFFF, 0xFFFFFFFF00000000,
+                 0x1FFFFFFF1FFFFFFF, 0xE0000000E0000000]
+        vals = []
+        for w in words:
+            for sh in range(nl):
+                v = sum(w << (64 * j) for j in range(nl) if j != sh) % mod
+                vals.append(v)
+        pats.append((mod, nl, vals))
+    for (mod, nl, vals), base in zip(pats, (0, 3)):
+        a = ints_to_limbs(vals, nl)
+        b = ints_to_limbs(list(reversed(vals)), nl)
+        fm = oracle.fr_from_mont if nl == 4 else oracle.fp_from_mont
+        tm = oracle.fr_to_mont if nl == 4 else oracle.fp_to_mont
+        am, bm = tm(a), tm(b)
+        for op, fn in ((0, lambda x, y: x * y % mod), (1, lambda x, y: (x + y) % mod), (2, lambda x, y: (x - y) % mod)):
+            got = limbs_to_ints(fm(ctx.field_op(base + op, am, bm)))
+            assert got == [fn(x, y) for x, y in zip(vals, reversed(vals))], (nl, op)
+            got2 = ctx.field_op(base + op, a, b)               # raw limbs as Montgomery residues
+            exp2 = tm(ints_to_limbs([fn(x, y) for x, y in zip(limbs_to_ints(fm(a)), limbs_to_ints(fm(b)))], nl))
+            assert np.array_equal(got2, exp2), (nl, op, "raw")
