@@ -226,6 +226,7 @@ def main():
             "vec_mul": (lambda: lib.pm_fr_vec_op_dev(h, 2, va._p, vb._p, pn, vo._p, pn, None), 96 * pn),
             "poly_evaluate": (lambda: lib.pm_fr_poly_evaluate_dev(h, va._p, pn, pp, ev.ctypes.data_as(C.POINTER(C.c_uint64)), None), 32 * pn),
             "poly_ruffini": (lambda: lib.pm_fr_poly_ruffini_dev(h, va._p, pn, pp, vo._p, None), 64 * pn),
+            "prefix_product": (lambda: lib.pm_fr_prefix_product_dev(h, va._p, pn, vo._p, None), 64 * pn),
             "batch_inverse": (lambda: lib.pm_fr_batch_inverse_dev(h, vo._p, pn, None), 64 * pn),
         }
         poly = {"n": pn, "note": "SURVEY 8f rows N1/N2 helpers; algorithmic bytes = operands read once + result written once"}

@@ -159,6 +159,9 @@ int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const u
  * remainder coeffs(z) is dropped, as upstream).  Not in place.  Returns after the work finished. */
 int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], void* d_out,
                            void* hip_stream);
+/* out[0] = 1, out[i] = in[0] * ... * in[i-1]: the grand-product accumulator z(X) of the permutation
+ * argument (dusk_plonk::permutation).  In place allowed. */
+int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n, void* d_out, void* hip_stream);
 /* util::batch_inversion: every non-zero element is replaced by its inverse, zeros stay zero. */
 int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, void* hip_stream);
 

@@ -41,6 +41,7 @@ SIGNATURES = {
                                    C.c_size_t, C.c_void_p]),
     "pm_fr_poly_evaluate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_void_p]),
     "pm_fr_poly_ruffini_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_void_p, C.c_void_p]),
+    "pm_fr_prefix_product_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pm_fr_batch_inverse_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),

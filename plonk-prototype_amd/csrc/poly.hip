@@ -267,6 +267,130 @@ __global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, size_t n, 
   }
 }
 
+// ------------------------------------------------------------------ prefix product
+// out[0] = 1, out[i] = prod_{j<i} a[j]: the grand-product accumulator z of the permutation
+// argument.  Work-efficient three-kernel scan; the products run in the device Montgomery domain.
+//   local : a tile of 256*PP_L elements is staged in LDS (coalesced), every thread multiplies its PP_L
+//           consecutive elements, the 256 thread totals are scanned (shuffles + LDS), and a second
+//           serial sweep writes the tile-local exclusive prefixes (48-byte entries) + the tile total
+//   carry : exclusive scan of the tile totals, pre-multiplied by the device->ABI constant
+//   final : out = local prefix * carry  (one product per element, lands in ABI form)
+constexpr int PP_L = 8;
+PM_DEV Fr fr_shfl_up_mul_scan(Fr v, u32 lane) {  // inclusive product scan inside a wave
+  for (int d = 1; d < 64; d <<= 1) {
+    Fr o = fr_shfl_up(v, d);
+    if (lane >= (u32)d) v = fe_mul<FrP>(v, o);
+  }
+  return v;
+}
+__global__ void __launch_bounds__(256) prefix_prod_local_kernel(const u32x4* in, size_t n, u32x4* tmp, u32x4* tile_tot) {
+  extern __shared__ u32 sh[];  // [9][256 * PP_L] limbs, then 4 * 9 words of wave totals
+  constexpr int TILE = 256 * PP_L;
+  u32* wave_tot = sh + 9 * TILE;
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const size_t base = (size_t)blockIdx.x * TILE;
+  const Fr to_dev = fe_pow2<FrP, 2 * 261 - 256>();
+  const Fr one = fe_one<FrP>();
+#pragma unroll
+  for (int j = 0; j < PP_L; ++j) {
+    const u32 e = j * 256 + t;
+    Fr u = one;                                            // past the end: neutral element
+    if (base + e < n) u = fe_mul<FrP>(ld_canon(in, base + e), to_dev);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh[i * TILE + e] = u.l[i];
+  }
+  __syncthreads();
+  Fr tot = one;
+#pragma unroll
+  for (int j = 0; j < PP_L; ++j) {
+    Fr u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u.l[i] = sh[i * TILE + t * PP_L + j];
+    tot = j == 0 ? u : fe_mul<FrP>(tot, u);
+  }
+  Fr incl = fr_shfl_up_mul_scan(tot, lane);
+  if (lane == 63) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wave_tot[wave * 9 + i] = incl.l[i];
+  }
+  Fr excl = fr_shfl_up(incl, 1);                           // exclusive inside the wave
+  if (lane == 0) excl = one;
+  __syncthreads();
+  Fr carry = one;
+  for (u32 w = 0; w < wave; ++w) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = wave_tot[w * 9 + i];
+    carry = fe_mul<FrP>(carry, o);
+  }
+  Fr run = fe_mul<FrP>(excl, carry);                       // product of everything before this thread
+#pragma unroll
+  for (int j = 0; j < PP_L; ++j) {
+    const u32 e = t * PP_L + j;
+    Fr u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u.l[i] = sh[i * TILE + e];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh[i * TILE + e] = run.l[i];   // exclusive prefix of element e
+    run = fe_mul<FrP>(run, u);
+  }
+  if (t == 255) st_tw(tile_tot, blockIdx.x, run);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PP_L; ++j) {                           // coalesced write-out
+    const u32 e = j * 256 + t;
+    if (base + e < n) {
+      Fr v;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v.l[i] = sh[i * TILE + e];
+      st_tw(tmp, base + e, v);
+    }
+  }
+}
+__global__ void __launch_bounds__(256) prefix_prod_carry_kernel(u32x4* tile_tot, u32 ntiles) {
+  __shared__ u32 sh[4 * 9 + 9];
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const Fr one = fe_one<FrP>();
+  const Fr to_abi = fe_pow2<FrP, 256>();
+  Fr run = one;
+  for (u32 base = 0; base < ntiles; base += 256) {
+    const u32 i = base + t;
+    Fr v = i < ntiles ? ld_tw(tile_tot, i) : one;
+    Fr incl = fr_shfl_up_mul_scan(v, lane);
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sh[wave * 9 + k] = incl.l[k];
+    }
+    Fr excl = fr_shfl_up(incl, 1);
+    if (lane == 0) excl = one;
+    __syncthreads();
+    Fr carry = run;
+    for (u32 w = 0; w < wave; ++w) {
+      Fr o;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) o.l[k] = sh[w * 9 + k];
+      carry = fe_mul<FrP>(carry, o);
+    }
+    excl = fe_mul<FrP>(excl, carry);
+    if (i < ntiles) st_tw(tile_tot, i, fr_canon(fe_mul<FrP>(excl, to_abi)));
+    if (t == 255) {
+      Fr all = fe_mul<FrP>(excl, v);                       // inclusive through the last tile of the group
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sh[36 + k] = all.l[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) run.l[k] = sh[36 + k];
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) prefix_prod_final_kernel(const u32x4* tmp, const u32x4* tile_carry, size_t n,
+                                                                 u32x4* out) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  st_canon(out, k, fe_mul<FrP>(ld_tw(tmp, k), ld_tw(tile_carry, k / (256 * PP_L))));
+}
+
 // ------------------------------------------------------------------ host helpers
 static void to_limbs29(u32* dst, HFr v) {  // ABI Montgomery -> device Montgomery limbs
   for (int i = 0; i < 5; ++i) v = host::add(v, v, host::FR());
@@ -451,6 +575,31 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   for (void* p : {zi_hi, zi_lo, z_hi, z_lo})
     if (p) (void)hipFree(p);
   return rc;
+}
+
+extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n, void* d_out, void* hip_stream) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return PM_OK;
+  if (!d_in || !d_out) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  const size_t tile = (size_t)256 * PP_L;
+  const u32 ntiles = (u32)((n + tile - 1) / tile);
+  int rc = ensure_buffer(ctx, ctx->poly_ws, (n + ntiles) * 48 + 64);
+  if (rc) return rc;
+  u32x4* tmp = (u32x4*)ctx->poly_ws.ptr;
+  u32x4* tile_tot = tmp + 3 * n;
+  const size_t lds = (9 * tile + 36) * 4;
+  PM_HIP(ctx, hipFuncSetAttribute((const void*)prefix_prod_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  ProfScope prof(ctx, st, "fr_prefix_product");
+  hipLaunchKernelGGL(prefix_prod_local_kernel, dim3(ntiles), dim3(256), lds, st, (const u32x4*)d_in, n, tmp, tile_tot);
+  hipLaunchKernelGGL(prefix_prod_carry_kernel, dim3(1), dim3(256), 0, st, tile_tot, ntiles);
+  hipLaunchKernelGGL(prefix_prod_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32x4*)tmp,
+                     (const u32x4*)tile_tot, n, (u32x4*)d_out);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
 }
 
 extern "C" int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, void* hip_stream) {

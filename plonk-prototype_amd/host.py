@@ -217,6 +217,13 @@ class Polynomial:
         ctx._check(ctx._lib.pm_fr_poly_ruffini_dev(ctx._h, self.vec._p, self.vec.n, _p(zz), out._p, None))
         return Polynomial(out)
 
+    def prefix_product(self) -> "Polynomial":
+        """[1, a0, a0 a1, ...]: the permutation argument's grand-product accumulator."""
+        ctx = self.vec.ctx
+        out = DeviceVector(ctx, self.vec.n)
+        ctx._check(ctx._lib.pm_fr_prefix_product_dev(ctx._h, self.vec._p, self.vec.n, out._p, None))
+        return Polynomial(out)
+
     def batch_inverse(self) -> "Polynomial":
         """In place; returns self."""
         ctx = self.vec.ctx

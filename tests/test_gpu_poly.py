@@ -73,6 +73,14 @@ def test_batch_inverse(ctx, oracle, n):
     assert np.array_equal(prod[nz], np.broadcast_to(one, (int(nz.sum()), 4))) and not prod[~nz].any()
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 5000, 1 << 16, (1 << 20) + 3, (1 << 21) + (1 << 19)])
+def test_prefix_product(ctx, oracle, n):
+    a = oracle.fr_sample(21 + n, n)
+    if n > 6000:
+        a[5000] = 0                                       # everything after a zero factor is zero
+    assert np.array_equal(_poly(ctx, a).prefix_product().to_host(), oracle.fr_prefix_product(a)), n
+
+
 def test_errors(ctx, oracle):
     import plonk_prototype_amd as pa
     a, b = _poly(ctx, oracle.fr_sample(1, 10)), _poly(ctx, oracle.fr_sample(2, 7))
