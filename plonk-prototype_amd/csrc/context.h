@@ -62,6 +62,7 @@ struct pm_ctx {
   long opt_msm_window_bits = 0;  // 0 = auto
   long opt_ntt_tile_log = 0;     // 0 = auto
   long opt_ntt_radix = 4;        // in-tile butterfly radix: 4 (4 elements per thread) or 8
+  long opt_ntt_xcd = 1;          // XCD-aware blockIdx -> tile mapping
   long opt_ntt_max_radix = 10;   // log2 of the largest pass radix (multi-pass plans)
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)

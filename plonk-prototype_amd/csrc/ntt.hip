@@ -315,7 +315,7 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
       a.pass_tw = dt->pass_tw[i];
       tw_flag = PASS_DIRECT_TW;
     }
-    a.flags = (i == 0 ? pre : 0u) | post_i | tw_flag;
+    a.flags = (i == 0 ? pre : 0u) | post_i | tw_flag | (ctx->opt_ntt_xcd ? PASS_XCD_REMAP : 0u);
     const unsigned threads = r4 ? pass4_threads(S, LT) : std::max(64u, (1u << (S + LT)) / 8);
     const size_t lds = r4 ? pass4_lds(S, LT) : pass_lds_bytes(S, LT);
     if (lds > 64 * 1024)

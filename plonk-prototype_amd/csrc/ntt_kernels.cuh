@@ -59,8 +59,18 @@ enum : u32 {
   PASS_PRE_COSET = 2u,   // multiply input i by g^i (coset_fft)
   PASS_POST_SCALE = 4u,  // multiply outputs by consts.scale (single-pass ifft; otherwise n^-1 is
                          // folded into the last pass's twiddle table)
-  PASS_POST_COSET = 8u,  // multiply output i by cs_hi/lo (coset_ifft; n^-1 folded in cs_hi)
+  PASS_POST_COSET = 8u,  // multiply output i by cs_hi/lo (coset_ifft)
+  PASS_XCD_REMAP = 16u,  // blockIdx -> tile so that each XCD walks a contiguous range of tiles
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Giving XCD x
+// the tiles [x*nb/8, (x+1)*nb/8) keeps neighbouring tiles -- which share the cache lines at their
+// common border in the blocked wide layout and read neighbouring twiddle-table lines -- behind one
+// L2.  Placement only changes speed, never results.
+PM_DEV u32 xcd_tile(u32 b, u32 nb, u32 flags) {
+  if (!(flags & PASS_XCD_REMAP) || (nb & 7u)) return b;
+  return (b & 7u) * (nb >> 3) + (b >> 3);
+}
 
 // ---- table entries: 9 limbs in 48 bytes -------------------------------------------------
 PM_DEV Fr ld_tw(const u32x4* tab, size_t idx) {
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 8 < 64 ? 64 : (1 << (S + LT)
   const u32 log_n = a.log_n;
   const size_t n = (size_t)1 << log_n;
   const size_t n_cols = (size_t)1 << (log_n - S);  // N / R
-  const size_t j0 = (size_t)blockIdx.x * T;
+  const size_t j0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, a.flags) * T;
 
   const Fr w8_1 = fr_limbs(kc.w8[0]);
   const Fr w8_2 = fr_limbs(kc.w8[1]);

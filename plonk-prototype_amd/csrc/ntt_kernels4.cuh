@@ -117,7 +117,7 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 4 < 64 ? 64 : (1 << (S + LT)
   const u32 log_n = a.log_n;
   const size_t n = (size_t)1 << log_n;
   const size_t n_cols = (size_t)1 << (log_n - S);
-  const size_t j0 = (size_t)blockIdx.x * T;
+  const size_t j0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, a.flags) * T;
   const Fr w4 = fr_limbs(kc.w8[1]);
 
   Fr x[4];

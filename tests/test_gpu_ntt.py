@@ -52,6 +52,18 @@ def test_plan_options(ctx, oracle, k, tile, maxr, radix):
         ctx.set_option("ntt_radix", 4)
 
 
+def test_xcd_mapping_is_result_neutral(ctx, oracle):
+    """blockIdx -> tile placement is a speed knob only."""
+    a = oracle.fr_sample(5, 1 << 16)
+    ctx.set_option("ntt_xcd", 0)
+    try:
+        off = [ctx.fr_ntt(a, 16, f) for f in ALL_FLAGS]
+    finally:
+        ctx.set_option("ntt_xcd", 1)
+    for f, x in zip(ALL_FLAGS, off):
+        assert np.array_equal(x, ctx.fr_ntt(a, 16, f)) and np.array_equal(x, oracle.fr_ntt(a, 16, f, 8))
+
+
 @pytest.mark.parametrize("k", [3, 4, 7, 9, 10, 11, 13, 14, 17])
 def test_radix8_family(ctx, oracle, k):
     """The radix-8 kernels (non-default) over single- and multi-pass sizes."""

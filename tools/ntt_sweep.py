@@ -39,7 +39,8 @@ for k in (3, 4, 5, 8, 9, 10, 11, 12, 13, 16, 20):
             ok = np.array_equal(ctx.fr_ntt(a, k, flags), o.fr_ntt(a, k, flags, 8))
             if not ok: print("RADIX4 MISMATCH", k, maxr, flags, flush=True)
 print("radix-4 check done", flush=True)
-for k in (20, 22, 24):
-    for radix in (8, 4):
-        for maxr, tile in ((10, 0), (8, 11), (8, 10), (7, 10)):
-            run(k, 1, 0, tile, maxr=maxr, radix=radix)
+for k in (16, 20, 22, 24):
+    for xcd in (0, 1, 0, 1):
+        ctx.set_option("ntt_xcd", xcd)
+        print("xcd", xcd, end=" ")
+        run(k, 1, 0, 0, maxr=10, radix=4)
