@@ -257,8 +257,27 @@ __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs
   bool first_run = true, have_head = false, have_tail = false;
   Xyzz acc = xyzz_identity();
   if (active) {
+    // software pipeline: the (key, value, point) of entry e+1 is requested before the ~5000
+    // instructions of entry e's addition, so the random 96-byte gather is never waited for
+    u32 nk = a.keys[lo], nv = a.vals[lo];
+    u32x4 nraw[6];
+    {
+      const u32x4* bp = a.bases + 6 * (size_t)(nv & 0x7fffffffu);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) nraw[i] = bp[i];
+    }
     for (size_t e = lo; e < hi; ++e) {
-      const u32 k = a.keys[e];
+      const u32 k = nk, v = nv;
+      u32x4 raw[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) raw[i] = nraw[i];
+      if (e + 1 < hi) {
+        nk = a.keys[e + 1];
+        nv = a.vals[e + 1];
+        const u32x4* bp = a.bases + 6 * (size_t)(nv & 0x7fffffffu);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nraw[i] = bp[i];
+      }
       if (k >= a.trash) break;  // sorted: only zero digits from here on
       if (k != cur) {
         if (cur != KEY_INVALID) {  // a run that ends inside the chunk
@@ -276,9 +295,13 @@ __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs
         cur = k;
         acc = xyzz_identity();
       }
-      const u32 v = a.vals[e];
-      const u32x4* bp = a.bases + 6 * (size_t)(v & 0x7fffffffu);
-      Fp x = fe_load<FpP>(bp), y = fe_load<FpP>(bp + 3);
+      u32 sx[12], sy[12];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        sx[4 * i] = raw[i].x; sx[4 * i + 1] = raw[i].y; sx[4 * i + 2] = raw[i].z; sx[4 * i + 3] = raw[i].w;
+        sy[4 * i] = raw[3 + i].x; sy[4 * i + 1] = raw[3 + i].y; sy[4 * i + 2] = raw[3 + i].z; sy[4 * i + 3] = raw[3 + i].w;
+      }
+      Fp x = fe_unpack<FpP>(sx), y = fe_unpack<FpP>(sy);
       u32 nz = 0;
 #pragma unroll
       for (int i = 0; i < 14; ++i) nz |= x.l[i] | y.l[i];
