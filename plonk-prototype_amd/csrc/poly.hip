@@ -80,7 +80,8 @@ PM_DEV Fr block_sum_256(Fr v, u32* sh /* 256 * 9 words */) {
 }
 // partial[b] = x^(b SEG) * sum_{i in segment b} c_i x^(i - b SEG),  SEG = 256 L, strided Horner
 __global__ void __launch_bounds__(256) poly_eval_kernel(const u32x4* coeffs, size_t n, u32 L, const EvalConsts kc,
-                                                         const u32x4* xpow /* x^t, t < 256 */, u32x4* partial) {
+                                                         const u32x4* xpow /* x^t, t < 256 */,
+                                                         const u32x4* xblk /* x^(b SEG) */, u32x4* partial) {
   __shared__ u32 sh[256 * 9];
   const u32 t = threadIdx.x, b = blockIdx.x;
   const size_t base = (size_t)b * 256 * L;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) poly_eval_kernel(const u32x4* coeffs, siz
   acc = fe_mul<FrP>(acc, ld_tw(xpow, t));
   acc = block_sum_256(acc, sh);
   if (t == 0) {
-    acc = fe_mul<FrP>(acc, fr_pow(fr_limbs(kc.xseg), b, fr_limbs(kc.one)));
+    acc = fe_mul<FrP>(acc, ld_tw(xblk, b));
     st_tw(partial, b, acc);
   }
 }
@@ -496,10 +497,11 @@ extern "C" int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t
   to_limbs29(kc.xrow, hfr_pow_u64(x, 256));
   to_limbs29(kc.xseg, hfr_pow_u64(x, seg));
   to_limbs29(kc.one, host::one(host::FR()));
-  int rc = ensure_buffer(ctx, ctx->poly_ws, (size_t)(256 + nblocks) * 48 + 64);
+  int rc = ensure_buffer(ctx, ctx->poly_ws, (size_t)(256 + 2 * (size_t)nblocks) * 48 + 64);
   if (rc) return rc;
   u32x4* xpow = (u32x4*)ctx->poly_ws.ptr;
-  u32x4* partial = xpow + 3 * 256;
+  u32x4* xblk = xpow + 3 * 256;
+  u32x4* partial = xblk + 3 * (size_t)nblocks;
   u32x4* d_out = partial + 3 * (size_t)nblocks;
   {
     NttConsts c;
@@ -507,11 +509,12 @@ extern "C" int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t
     memcpy(c.w8[0], kc.x, sizeof kc.x);
     memcpy(c.scale, kc.one, sizeof kc.one);
     hipLaunchKernelGGL(pow_table_kernel, dim3(1), dim3(256), 0, st, xpow, c, 256u, 1u);
+    hipLaunchKernelGGL(pow_table_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, st, xblk, c, nblocks, (u32)seg);
   }
   {
     ProfScope prof(ctx, st, "fr_poly_evaluate");
     hipLaunchKernelGGL(poly_eval_kernel, dim3(nblocks), dim3(256), 0, st, (const u32x4*)d_coeffs, n, L, kc,
-                       (const u32x4*)xpow, partial);
+                       (const u32x4*)xpow, (const u32x4*)xblk, partial);
     hipLaunchKernelGGL(poly_eval_final_kernel, dim3(1), dim3(256), 0, st, (const u32x4*)partial, nblocks, d_out);
   }
   PM_HIP(ctx, hipGetLastError());
