@@ -184,6 +184,21 @@ def main():
                             "traffic": (json.load(open(tpath)).get(f"msm_accumulate_l1_2^{mk}")
                                         if tpath_exists and world == 1 else None)}}
         assert ok, "MSM result differs from the discrete-log identity"
+        if table and world == 1 and mk <= 20:
+            # a prover round: 4 wire polynomials committed in one pass over the same SRS
+            kb = 4
+            sc4 = np.concatenate([sc] + [oracle.fr_sample(0x5343414D + j, mn) for j in range(1, kb)])
+            d_sc4 = torch.from_numpy(np.ascontiguousarray(sc4).view(np.int64)).to(dev)
+            r4 = bases.msm_batch_dev(d_sc4.data_ptr(), mn, kb)
+            assert np.array_equal(r4[0], res), "batched commit differs from the single one"
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                bases.msm_batch_dev(d_sc4.data_ptr(), mn, kb)
+            barrier()
+            bdt = time.perf_counter() - t0
+            out["batch4"] = {"ms_per_msm": bdt / steps / kb * 1e3, "value": mn * kb * steps / bdt,
+                             "note": "4 scalar vectors per call over the resident SRS (pm_g1_msm_batch_dev)"}
         bases.free()
         return out, pts, sc
 

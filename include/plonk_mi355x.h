@@ -131,6 +131,14 @@ int pm_g1_msm_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n,
                   const void* d_scalars, uint32_t scalar_form, uint64_t out_xyz[18],
                   void* hip_stream);
 
+/* `batch` MSMs over the SAME bases in one pass (a prover round commits to 4-6 polynomials of one
+ * size): scalar vector j starts at d_scalars + 32 * j * scalar_stride, result j at out_xyz + 18 j.
+ * The sort and the additions scale with the batch, the latency-bound tail (bucket reduction, host
+ * fold) is paid once.  batch <= 64. */
+int pm_g1_msm_batch_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars,
+                        size_t scalar_stride, uint32_t batch, uint32_t scalar_form, uint64_t* out_xyz,
+                        void* hip_stream);
+
 /* out = sum of k projective points (the group-law "all-reduce" after an all-gather). Host. */
 int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]);
 

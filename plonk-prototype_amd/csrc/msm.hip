@@ -43,7 +43,8 @@ static constexpr u32 KEY_INVALID = 0xffffffffu;
 struct MsmGeom {
   u32 c;         // window bits
   u32 nwin;      // digit windows
-  u32 nsets;     // bucket sets: nwin, or 1 when the bases carry a table of 2^(c w) P
+  u32 nsets;     // bucket sets per MSM: nwin, or 1 when the bases carry a table of 2^(c w) P
+  u32 batch;     // MSMs sharing the bases in this launch sequence (their sets are laid side by side)
   u32 bbits;     // c - 1: bits of the bucket field
   u32 nbuckets;  // 1 << bbits per set
   u32 key_bits;  // bits of a sort key (set || bucket, plus room for the trash key)
@@ -51,7 +52,7 @@ struct MsmGeom {
   u32 row_stride;  // table mode: points per table row (value = window * row_stride + index)
 };
 
-static MsmGeom make_geom(size_t n, long opt_c, u32 table_c, size_t table_stride) {
+static MsmGeom make_geom(size_t n, long opt_c, u32 table_c, size_t table_stride, u32 batch) {
   MsmGeom g;
   u32 lg = 0;
   while (((size_t)1 << (lg + 1)) <= std::max<size_t>(n, 1)) ++lg;
@@ -60,12 +61,13 @@ static MsmGeom make_geom(size_t n, long opt_c, u32 table_c, size_t table_stride)
   g.c = (u32)c;
   g.nwin = (256 + g.c - 1) / g.c;
   g.nsets = table_c ? 1u : g.nwin;
+  g.batch = batch;
   g.bbits = g.c - 1;
   g.nbuckets = 1u << g.bbits;
   u32 wb = 0;
-  while ((1u << wb) < g.nsets + 1) ++wb;  // room for set == nsets (trash)
+  while ((1u << wb) < g.nsets * batch + 1) ++wb;  // room for set == nsets * batch (trash)
   g.key_bits = g.bbits + wb;
-  g.trash = g.nsets << g.bbits;
+  g.trash = (g.nsets * batch) << g.bbits;
   g.row_stride = (u32)table_stride;
   return g;
 }
@@ -146,11 +148,14 @@ __global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scr
 }
 
 // ------------------------------------------------------------------ 1: digits
-__global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_form, MsmGeom g, u32 offset,
-                                  u32* keys, u32* vals) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fr s = fe_load<FrP>(scalars + 2 * i);
+__global__ void msm_digits_kernel(const u32x4* scalars, size_t n, size_t sc_stride, u32 scalar_form, MsmGeom g,
+                                  u32 offset, u32* keys, u32* vals) {
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over batch * n
+  const size_t total = (size_t)g.batch * n;
+  if (gi >= total) return;
+  const u32 j = (u32)(gi / n);          // which MSM of the batch
+  const size_t i = gi - (size_t)j * n;  // which scalar / base
+  Fr s = fe_load<FrP>(scalars + 2 * ((size_t)j * sc_stride + i));
   // Montgomery (x * 2^256): multiply by 2^5 / 2^261 -> x.   Canonical: multiply by one -> x mod r.
   Fr f;
   if (scalar_form == PM_SCALAR_MONTGOMERY) {
@@ -165,8 +170,8 @@ __global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_for
   u32 carry = 0;
   const u32 half = 1u << g.bbits;
   for (u32 k = 0; k < g.nwin; ++k) {
-    const u32 lo = k * g.c, j = lo >> 5, sh = lo & 31;
-    u64 two = (u64)w[j] | ((u64)(j + 1 < 9 ? w[j + 1] : 0u) << 32);
+    const u32 lo = k * g.c, word = lo >> 5, sh = lo & 31;
+    u64 two = (u64)w[word] | ((u64)(word + 1 < 9 ? w[word + 1] : 0u) << 32);
     u32 d = (u32)(two >> sh) & ((1u << g.c) - 1u);
     d += carry;
     u32 neg = 0;
@@ -177,13 +182,10 @@ __global__ void msm_digits_kernel(const u32x4* scalars, size_t n, u32 scalar_for
     } else {
       carry = 0;
     }
-    if (g.nsets == 1) {  // table of 2^(c k) P: every window feeds the one bucket set
-      keys[(size_t)k * n + i] = d ? (d - 1) : g.trash;
-      vals[(size_t)k * n + i] = (k * g.row_stride + offset + (u32)i) | (neg << 31);
-    } else {
-      keys[(size_t)k * n + i] = d ? ((k << g.bbits) | (d - 1)) : g.trash;
-      vals[(size_t)k * n + i] = (offset + (u32)i) | (neg << 31);
-    }
+    const u32 set = j * g.nsets + (g.nsets == 1 ? 0u : k);
+    keys[(size_t)k * total + gi] = d ? ((set << g.bbits) | (d - 1)) : g.trash;
+    // table of 2^(c k) P (nsets == 1): every window feeds the one bucket set of its MSM
+    vals[(size_t)k * total + gi] = ((g.nsets == 1 ? k * g.row_stride : 0u) + offset + (u32)i) | (neg << 31);
   }
 }
 
@@ -485,17 +487,20 @@ static XYZZ projective_to_xyzz(const uint64_t* xyz) {  // homogeneous (X/Z, Y/Z)
 // ------------------------------------------------------------------ driver
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars,
-            u32 scalar_form, uint64_t out_xyz[18], hipStream_t st) {
+int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars, size_t sc_stride,
+            u32 batch, u32 scalar_form, uint64_t* out_xyz /* batch x 18 */, hipStream_t st) {
+  if (batch == 0) return PM_OK;
   if (n == 0) {
-    write_projective(out_xyz, host::xyzz_identity());
+    for (u32 j = 0; j < batch; ++j) write_projective(out_xyz + 18 * j, host::xyzz_identity());
     return PM_OK;
   }
   if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
   if (bases->table_c && (size_t)bases->n * ((256 + bases->table_c - 1) / bases->table_c) > 0x7fffffffu)
     return set_err(ctx, PM_ERR_BAD_ARG, "window table too large for 31-bit point indices");
-  const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n);
-  const size_t m = n * g.nwin;  // (key, value) pairs
+  const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
+  const size_t m = n * batch * g.nwin;  // (key, value) pairs
+  const u32 nsets_all = g.nsets * batch;
+  if (m > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "batch * n * windows exceeds 2^31 pairs");
   // chunk sizes: level 1 reads L1 sorted pairs per thread; deeper levels read LN slots of the
   // (mostly empty) partial list, shifted by LN/2 so that the two slots a wave boundary leaves
   // behind (tail of lane 63, head of the next lane 0) fall into the same chunk
@@ -503,7 +508,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   // the mean run length m / #buckets -- a chunk not much longer than the runs leaves pass-through
   // partials for the latency-bound follow-up levels (0.2 ms of them at a ratio of 4.7, 0.75 ms at
   // 2.5) -- at least 128, and never so long that the grid drops below 2^17 threads.
-  const size_t avg_run = std::max<size_t>(1, m / ((size_t)g.nbuckets * g.nsets));
+  const size_t avg_run = std::max<size_t>(1, m / ((size_t)g.nbuckets * nsets_all));
   const u32 L1 = ctx->opt_msm_chunk
                      ? (u32)ctx->opt_msm_chunk
                      : (u32)std::max<size_t>(16, std::min<size_t>(m >> 17, std::max<size_t>(128, 4 * avg_run)));
@@ -519,10 +524,10 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
       if (len <= 32) break;  // the next level is a single thread
     }
   }
-  const size_t total_buckets = (size_t)g.nbuckets * g.nsets;
+  const size_t total_buckets = (size_t)g.nbuckets * nsets_all;
   const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : 8u, g.nbuckets);
   const u32 chunks_per_win = g.nbuckets / LB;
-  const size_t total_chunks = (size_t)chunks_per_win * g.nsets;
+  const size_t total_chunks = (size_t)chunks_per_win * nsets_all;
 
   // workspace layout
   size_t sort_tmp = 0;
@@ -543,8 +548,8 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     o_ppts[i] = take(lens[i] * 256);
   }
   const size_t o_red = take(total_chunks * 256);
-  const size_t o_red2 = take((total_chunks / 256 + g.nsets) * 256);
-  const size_t o_win = take((size_t)g.nsets * 256);
+  const size_t o_red2 = take((total_chunks / 256 + nsets_all) * 256);
+  const size_t o_win = take((size_t)nsets_all * 256);
   int rc = ensure_buffer(ctx, ctx->msm_ws, off);
   if (rc) return rc;
   char* ws = (char*)ctx->msm_ws.ptr;
@@ -552,16 +557,18 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   u32 *keys1 = (u32*)(ws + o_keys1), *vals1 = (u32*)(ws + o_vals1);
   u32x4* buckets = (u32x4*)(ws + o_buckets);
 
-  if (!ctx->msm_host_pinned) {
-    PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, 64 * 256, hipHostMallocDefault));
-    ctx->msm_host_pinned_bytes = 64 * 256;
+  if (ctx->msm_host_pinned_bytes < (size_t)nsets_all * 256) {
+    if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
+    ctx->msm_host_pinned = nullptr;
+    ctx->msm_host_pinned_bytes = std::max<size_t>(64, nsets_all) * 256;
+    PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, ctx->msm_host_pinned_bytes, hipHostMallocDefault));
   }
 
   // 1 digits
   {
   ProfScope prof(ctx, st, "msm_digits");
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                     (const u32x4*)d_scalars, n, scalar_form, g, (u32)offset, keys0, vals0);
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n * batch + 255) / 256)), dim3(256), 0, st,
+                     (const u32x4*)d_scalars, n, sc_stride, scalar_form, g, (u32)offset, keys0, vals0);
   }
   PM_HIP(ctx, hipGetLastError());
   // 2 sort
@@ -621,27 +628,29 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     const u32 per1 = std::min<u32>(256, chunks_per_win);
     const u32 groups = chunks_per_win / per1;  // per window
     if (groups > 1) {
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nsets * groups), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(nsets_all * groups), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
                          (u32x4*)(ws + o_red2), 0u);
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nsets), dim3(64), 0, st, (const u32x4*)(ws + o_red2), groups,
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(nsets_all), dim3(64), 0, st, (const u32x4*)(ws + o_red2), groups,
                          (u32x4*)(ws + o_win), 1u);
     } else {
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(g.nsets), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
+      hipLaunchKernelGGL(msm_sum_kernel, dim3(nsets_all), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
                          (u32x4*)(ws + o_win), 1u);
     }
   }
   PM_HIP(ctx, hipGetLastError());
   // 5 host fold
-  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)g.nsets * 256, hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)nsets_all * 256, hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
   const u32* hw = (const u32*)ctx->msm_host_pinned;
-  XYZZ total = host::xyzz_identity();
-  for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no doublings at all
-    if (w + 1 < g.nsets)
-      for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
-    total = host::xyzz_add(total, xyzz_to_host(hw + 64 * w));
+  for (u32 j = 0; j < batch; ++j) {
+    XYZZ total = host::xyzz_identity();
+    for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no doublings at all
+      if (w + 1 < g.nsets)
+        for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
+      total = host::xyzz_add(total, xyzz_to_host(hw + 64 * ((size_t)j * g.nsets + w)));
+    }
+    write_projective(out_xyz + 18 * j, total);
   }
-  write_projective(out_xyz, total);
   return PM_OK;
 }
 
@@ -760,7 +769,22 @@ extern "C" int pm_g1_msm_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, 
     return set_err(ctx, PM_ERR_LENGTH, "more scalars than uploaded bases");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  return msm_run(ctx, bases, offset, n, d_scalars, scalar_form, out_xyz, st);
+  return msm_run(ctx, bases, offset, n, d_scalars, n, 1, scalar_form, out_xyz, st);
+}
+
+extern "C" int pm_g1_msm_batch_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars,
+                                   size_t scalar_stride, uint32_t batch, uint32_t scalar_form, uint64_t* out_xyz,
+                                   void* hip_stream) {
+  if (!ctx || !bases || !out_xyz || (!d_scalars && n && batch)) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (scalar_form > PM_SCALAR_CANONICAL) return set_err(ctx, PM_ERR_BAD_ARG, "scalar_form");
+  if (offset > bases->n || n > bases->n - offset)
+    return set_err(ctx, PM_ERR_LENGTH, "more scalars than uploaded bases");
+  if (batch > 1 && scalar_stride < n) return set_err(ctx, PM_ERR_BAD_ARG, "scalar_stride shorter than n");
+  if (batch > 64) return set_err(ctx, PM_ERR_BAD_ARG, "batch > 64");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  return msm_run(ctx, bases, offset, n, d_scalars, scalar_stride, batch, scalar_form, out_xyz, st);
 }
 
 extern "C" int pm_g1_msm(pm_ctx* ctx, const pm_bases* bases, size_t n, const uint64_t* scalars,
@@ -775,7 +799,7 @@ extern "C" int pm_g1_msm(pm_ctx* ctx, const pm_bases* bases, size_t n, const uin
     if (rc) return rc;
     PM_HIP(ctx, hipMemcpyAsync(ctx->msm_scalars.ptr, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
   }
-  return msm_run(ctx, bases, 0, n, ctx->msm_scalars.ptr, scalar_form, out_xyz, ctx->stream);
+  return msm_run(ctx, bases, 0, n, ctx->msm_scalars.ptr, n, 1, scalar_form, out_xyz, ctx->stream);
 }
 
 extern "C" int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]) {

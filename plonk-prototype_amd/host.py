@@ -359,6 +359,19 @@ class Bases:
         return out
 
 
+def _msm_batch_dev(self, d_scalars: int, n: int, batch: int, stride: int | None = None, offset: int = 0,
+                   scalar_form: int = _lib.SCALAR_MONTGOMERY, stream: int = 0) -> np.ndarray:
+    """`batch` MSMs over the same bases in one pass -> [batch, 18]."""
+    out = np.zeros((batch, 18), np.uint64)
+    self.ctx._check(self.ctx._lib.pm_g1_msm_batch_dev(
+        self.ctx._h, self._h, offset, n, C.c_void_p(d_scalars), stride if stride is not None else n, batch,
+        scalar_form, _p(out), C.c_void_p(stream)))
+    return out
+
+
+Bases.msm_batch_dev = _msm_batch_dev
+
+
 def msm_variable_base(points, scalars, ctx: Context | None = None,
                       scalar_form: int = _lib.SCALAR_MONTGOMERY) -> np.ndarray:
     """``dusk_bls12_381::multiscalar_mul::msm_variable_base(points, scalars) -> G1Projective``.
@@ -409,6 +422,19 @@ class CommitKey:
 
     def max_degree(self) -> int:
         return self._bases.n - 1
+
+    def commit_many(self, polys) -> np.ndarray:
+        """Commit to several polynomials of one length in one pass -> [k, 12] affine."""
+        c = np.ascontiguousarray(polys, dtype=np.uint64)
+        k, n = c.shape[0], c.shape[1]
+        if n > self._bases.n:
+            raise Error(_lib.PM_ERR_LENGTH, "PolynomialDegreeTooLarge")
+        d = DeviceVector.from_host(self.ctx, c.reshape(-1, 4))
+        try:
+            xyz = self._bases.msm_batch_dev(d.ptr, n, k)
+        finally:
+            d.free()
+        return np.stack([g1_to_affine(x)[0] for x in xyz])
 
     def commit(self, coeffs) -> np.ndarray:
         """-> Commitment as affine G1 [12] ((0, 0) for the zero polynomial)."""

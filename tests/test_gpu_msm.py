@@ -146,6 +146,26 @@ def test_precomputed_window_table(ctx, oracle, c):
     assert np.array_equal(pa.g1_to_affine(bases.msm(eq))[0], oracle.g1_msm(pts, eq, SCALAR_MONTGOMERY, 8))
 
 
+@pytest.mark.parametrize("table", [False, True])
+def test_batched_commits(ctx, oracle, table):
+    """pm_g1_msm_batch_dev: k scalar vectors over one SRS in a single pass == k separate MSMs."""
+    import plonk_prototype_amd as pa
+    n, k = 3000, 5
+    pts, sc0 = _edge_inputs(oracle, n, 311)
+    polys = np.stack([sc0] + [oracle.fr_sample(400 + j, n) for j in range(k - 1)])
+    polys[2][:] = polys[2][0]                                       # one skewed vector in the batch
+    polys[3][::2] = 0
+    ck = pa.CommitKey(pts, ctx, precompute=table)
+    got = ck.commit_many(polys)
+    for j in range(k):
+        assert np.array_equal(got[j], oracle.g1_msm(pts, polys[j], SCALAR_MONTGOMERY, 8)), (table, j)
+    short = ck.commit_many(polys[:, :1000])                          # prefix of the SRS, like commit()
+    for j in range(k):
+        assert np.array_equal(short[j], oracle.g1_msm(pts[:1000], polys[j, :1000], SCALAR_MONTGOMERY, 8))
+    with pytest.raises(pa.Error):
+        ck.commit_many(np.zeros((2, n + 1, 4), np.uint64))
+
+
 def test_sharded_msm_fold(ctx, oracle):
     """The multi-GPU decomposition on one GPU: shard by points, fold the partials."""
     import plonk_prototype_amd as pa
