@@ -173,6 +173,64 @@ int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n, void* d_ou
 /* util::batch_inversion: every non-zero element is replaced by its inverse, zeros stay zero. */
 int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, void* hip_stream);
 
+/* ---- PLONK prover rounds (BASELINE.json configs[3]) ----------- */
+/* The pointwise work of dusk_plonk::proof_system::{permutation, quotient_poly, linearisation_poly}
+ * (dusk-plonk 0.8.2, ref:Cargo.toml:19) for a 4-wire arithmetic circuit
+ *   q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + PI = 0
+ * with copy constraints over the cosets {1, k1, k2, k3} H, fused into one kernel per round so that
+ * every polynomial stays in HBM between the NTT and MSM calls.  Vectors are canonical Fr in device
+ * memory; challenges and constants are host Fr (Montgomery limbs). */
+
+/* out[i] = scale * base^i, i < n: domain.elements(), the 4n-coset points g w^i, powers of a challenge. */
+int pm_fr_powers_dev(pm_ctx* ctx, const uint64_t base[4], const uint64_t scale[4], size_t n, void* d_out,
+                     void* hip_stream);
+
+/* out = sum_j coeffs[j] * vecs[j], k <= PM_LINCOMB_MAX vectors of n elements (d_vecs: host array of
+ * device pointers): the linearisation polynomial and the aggregated opening polynomial. */
+#define PM_LINCOMB_MAX 16
+int pm_fr_lincomb_dev(pm_ctx* ctx, uint32_t k, const void* const* d_vecs, const uint64_t* coeffs, size_t n,
+                      void* d_out, void* hip_stream);
+
+/* Permutation argument, per row i < n of the domain H (x_i = roots[i] = w^i):
+ *   num[i] = prod_j (wires[j][i] + beta k_j x_i + gamma),   k_0 = 1
+ *   den[i] = prod_j (wires[j][i] + beta sigmas[j][i] + gamma)
+ * z = prefix_product(num / den) (pm_fr_batch_inverse_dev, pm_fr_vec_op_dev, pm_fr_prefix_product_dev). */
+typedef struct pm_plonk_perm_args {
+  const void* wires[4];   /* a, b, c, d evaluations on H */
+  const void* sigmas[4];  /* sigma_1..4 evaluations on H */
+  const void* roots;      /* w^i */
+  uint64_t beta[4], gamma[4];
+  uint64_t k[3][4];       /* coset representatives k1, k2, k3 (dusk: 7, 13, 17) */
+} pm_plonk_perm_args;
+int pm_plonk_perm_terms_dev(pm_ctx* ctx, const pm_plonk_perm_args* args, size_t n, void* d_num, void* d_den,
+                            void* hip_stream);
+
+/* Quotient numerator divided by Z_H, pointwise on the 4n coset (x_i = g w_4n^i, i < 4n):
+ *   t[i] = zh_inv[i mod 4] * ( q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + pi
+ *          + alpha   ( z[i]   prod_j (w_j + beta k_j x_i + gamma)
+ *                    - z[i+4] prod_j (w_j + beta sigma_j + gamma) )
+ *          + alpha^2 ( z[i] - 1 ) l1[i] )
+ * (index i+4 wraps: z(w X) on the 4n coset).  coset_ifft of t gives the quotient polynomial. */
+typedef struct pm_plonk_quotient_args {
+  const void* wires[4];
+  const void* z;
+  const void* q_m;
+  const void* q_l;
+  const void* q_r;
+  const void* q_o;
+  const void* q_4;
+  const void* q_c;
+  const void* pi;         /* public-input polynomial on the coset */
+  const void* sigmas[4];
+  const void* l1;         /* first Lagrange polynomial on the coset */
+  const void* x;          /* the coset points g w_4n^i */
+  uint64_t alpha[4], beta[4], gamma[4];
+  uint64_t k[3][4];
+  uint64_t zh_inv[4][4];  /* 1 / (x_i^n - 1), which only depends on i mod 4 */
+} pm_plonk_quotient_args;
+int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, void* d_out,
+                          void* hip_stream);
+
 /* ---- introspection / tuning (not needed by the prover) --------------------------------- */
 
 /* Number of kernel launches and the Stockham radices the library will use for 2^log_n. */

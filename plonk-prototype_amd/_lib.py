@@ -10,6 +10,25 @@ LIB_PATH = os.path.join(_HERE, "lib", "libplonk_mi355x.so")
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
 
+
+
+class PermArgs(C.Structure):
+    """``pm_plonk_perm_args``"""
+    _fields_ = [("wires", C.c_void_p * 4), ("sigmas", C.c_void_p * 4), ("roots", C.c_void_p),
+                ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4), ("k", (C.c_uint64 * 4) * 3)]
+
+
+class QuotientArgs(C.Structure):
+    """``pm_plonk_quotient_args``"""
+    _fields_ = [("wires", C.c_void_p * 4), ("z", C.c_void_p), ("q_m", C.c_void_p), ("q_l", C.c_void_p),
+                ("q_r", C.c_void_p), ("q_o", C.c_void_p), ("q_4", C.c_void_p), ("q_c", C.c_void_p),
+                ("pi", C.c_void_p), ("sigmas", C.c_void_p * 4), ("l1", C.c_void_p), ("x", C.c_void_p),
+                ("alpha", C.c_uint64 * 4), ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4),
+                ("k", (C.c_uint64 * 4) * 3), ("zh_inv", (C.c_uint64 * 4) * 4)]
+
+
+LINCOMB_MAX = 16
+
 # name -> (restype, argtypes); must list every function the header declares
 SIGNATURES = {
     "pm_version": (C.c_char_p, []),
@@ -45,6 +64,12 @@ SIGNATURES = {
     "pm_fr_poly_ruffini_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, C.c_void_p, C.c_void_p]),
     "pm_fr_prefix_product_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pm_fr_batch_inverse_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pm_fr_powers_dev": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pm_fr_lincomb_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), u64p, C.c_size_t, C.c_void_p,
+                                    C.c_void_p]),
+    "pm_plonk_perm_terms_dev": (C.c_int, [C.c_void_p, C.POINTER(PermArgs), C.c_size_t, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "pm_plonk_quotient_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientArgs), C.c_size_t, C.c_void_p, C.c_void_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     "pm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,0 +1,289 @@
+// The pointwise work of the PLONK prover rounds between the NTT and MSM calls, one fused kernel per
+// round (BASELINE.json configs[3] "Full PLONK prove"):
+//   pm_fr_powers_dev         domain.elements(), coset points, powers of a challenge
+//   pm_fr_lincomb_dev        linearisation polynomial / aggregated opening polynomial
+//   pm_plonk_perm_terms_dev  numerator and denominator of the permutation grand product
+//   pm_plonk_quotient_dev    quotient numerator / Z_H on the 4n coset
+// Restates dusk_plonk::proof_system::{permutation, quotient_poly, linearisation_poly} of
+// dusk-plonk 0.8.2 (ref:Cargo.toml:19; not in the reference tree) for the arithmetic and
+// permutation identities; range / logic / curve-addition widgets are not built.
+//
+// Scaling bookkeeping (poly_common.cuh): memory holds ABI form (x 2^256); a product of forms 2^a and
+// 2^b is of form 2^(a+b-261).  Wires are moved to device form (2^261) once per point, challenges are
+// prepared by the host in the form that makes every sum homogeneous, the result leaves in ABI form.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "context.h"
+#include "host_field.h"
+#include "ntt_kernels.cuh"
+#include "poly_common.cuh"
+
+namespace pm {
+
+// ABI (canonical) -> device form, (1, <1.01)
+PM_DEV Fr to_dev(const Fr& x) { return fe_reduce_weak<FrP>(fr_shl5(x)); }
+
+struct RoundConsts {
+  u32 beta_k[4][9];  // beta k_j 2^266  (k_0 = 1):  x ABI  -> device form
+  u32 beta[9];       // beta 2^266:                 sigma ABI -> device form
+  u32 gamma[9];      // gamma 2^261
+  u32 alpha[9];      // alpha 2^261
+  u32 alpha2[9];     // alpha^2 2^266:              (ABI x ABI = 2^251) -> ABI
+  u32 one_abi[9];    // 2^256
+  u32 zh_inv[4][9];  // 1 / Z_H(x_i) by i mod 4, 2^261
+};
+
+// w + beta k x + gamma, all in device form: value < 1.01 r + 2 r + r, limbs < 3 * 2^29
+PM_DEV Fr perm_factor(const Fr& w_dev, const Fr& x_abi, const u32* bk, const Fr& gamma) {
+  return fe_add<FrP>(fe_add<FrP>(w_dev, fe_mul<FrP>(x_abi, fr_limbs(bk))), gamma);
+}
+// product of four factors (value < 4.1 r, limbs < 3 * 2^29 each) -> device form, (1, <1.1)
+PM_DEV Fr prod4(const Fr& f0, const Fr& f1, const Fr& f2, const Fr& f3) {
+  Fr p = fe_mul<FrP>(f0, fe_norm<FrP>(f1));   // 4.1^2 / 70 + 1 < 1.3
+  p = fe_mul<FrP>(f2, p);
+  return fe_mul<FrP>(f3, p);
+}
+
+// ------------------------------------------------------------------ powers
+__global__ void __launch_bounds__(256) powers_kernel(u32x4* out, size_t n, const NttConsts c /* w8[0] = base,
+                                                     w8[1] = base^T, scale, one = 2^256 */) {
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Fr cur = fr_pow(fr_limbs(c.w8[0]), t, fr_limbs(c.scale));
+  const Fr step = fr_limbs(c.w8[1]), one_abi = fr_limbs(c.one);
+  for (size_t i = t; i < n; i += T) {
+    st_canon(out, i, fe_mul<FrP>(cur, one_abi));
+    cur = fe_mul<FrP>(cur, step);
+  }
+}
+
+// ------------------------------------------------------------------ linear combination
+struct LincombArgs {
+  const u32x4* v[PM_LINCOMB_MAX];
+  u32 c[PM_LINCOMB_MAX][9];   // device form
+  u32 k;
+};
+__global__ void __launch_bounds__(256) lincomb_kernel(const LincombArgs a, u32x4* out, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    Fr acc = fe_mul<FrP>(ld_canon(a.v[0], i), fr_limbs(a.c[0]));
+    for (u32 j = 1; j < a.k; ++j)
+      acc = fe_reduce_weak<FrP>(fe_add<FrP>(acc, fe_mul<FrP>(ld_canon(a.v[j], i), fr_limbs(a.c[j]))));
+    st_canon(out, i, acc);
+  }
+}
+
+// ------------------------------------------------------------------ permutation terms
+struct PermPtrs {
+  const u32x4* w[4];
+  const u32x4* s[4];
+  const u32x4* roots;
+  u32x4* num;
+  u32x4* den;
+};
+__global__ void __launch_bounds__(256) perm_terms_kernel(const PermPtrs p, const RoundConsts kc, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const Fr gamma = fr_limbs(kc.gamma), one_abi = fr_limbs(kc.one_abi);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const Fr x = ld_canon(p.roots, i);
+    Fr w[4], f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = to_dev(ld_canon(p.w[j], i));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = perm_factor(w[j], x, kc.beta_k[j], gamma);
+    st_canon(p.num, i, fe_mul<FrP>(prod4(f[0], f[1], f[2], f[3]), one_abi));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = perm_factor(w[j], ld_canon(p.s[j], i), kc.beta, gamma);
+    st_canon(p.den, i, fe_mul<FrP>(prod4(f[0], f[1], f[2], f[3]), one_abi));
+  }
+}
+
+// ------------------------------------------------------------------ quotient
+struct QuotPtrs {
+  const u32x4* w[4];
+  const u32x4* z;
+  const u32x4 *q_m, *q_l, *q_r, *q_o, *q_4, *q_c, *pi;
+  const u32x4* s[4];
+  const u32x4* l1;
+  const u32x4* x;
+  u32x4* out;
+};
+__global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const RoundConsts kc, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;   // a multiple of 4: i mod 4 is fixed per thread
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 r4 = (u32)(t0 & 3);
+  Fr zhi;
+#pragma unroll
+  for (int l = 0; l < 9; ++l)
+    zhi.l[l] = r4 == 0 ? kc.zh_inv[0][l] : (r4 == 1 ? kc.zh_inv[1][l] : (r4 == 2 ? kc.zh_inv[2][l] : kc.zh_inv[3][l]));
+  const Fr gamma = fr_limbs(kc.gamma);
+  for (size_t i = t0; i < n4; i += stride) {
+    const size_t inext = i + 4 < n4 ? i + 4 : i + 4 - n4;
+    Fr w[4], f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = to_dev(ld_canon(p.w[j], i));
+    // arithmetic identity, ABI form: five (1, <2) products and two canonical loads -> (7, <12)
+    Fr g = fe_mul<FrP>(ld_canon(p.q_m, i), fe_mul<FrP>(w[0], w[1]));
+    g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_l, i), w[0]));
+    g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_r, i), w[1]));
+    g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_o, i), w[2]));
+    g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_4, i), w[3]));
+    g = fe_norm<FrP>(fe_add<FrP>(g, fe_add<FrP>(ld_canon(p.q_c, i), ld_canon(p.pi, i))));   // limbs back to (1)
+    // permutation identity
+    const Fr x = ld_canon(p.x, i);
+    const Fr z = ld_canon(p.z, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = perm_factor(w[j], x, kc.beta_k[j], gamma);
+    const Fr idz = fe_mul<FrP>(z, prod4(f[0], f[1], f[2], f[3]));                          // ABI (1, <2)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = perm_factor(w[j], ld_canon(p.s[j], i), kc.beta, gamma);
+    const Fr cpz = fe_mul<FrP>(ld_canon(p.z, inext), prod4(f[0], f[1], f[2], f[3]));      // ABI (1, <2)
+    // idz - cpz + 3r: (4, <5); times alpha -> ABI (1, <2)
+    g = fe_add<FrP>(g, fe_mul<FrP>(fe_sub<FrP, 3, 1>(idz, cpz), fr_limbs(kc.alpha)));
+    // (z - 1) l1 alpha^2:  z - 1 + 2r is (4, <3); product with ABI l1 is 2^251, alpha2 restores 2^256
+    const Fr zm1 = fe_sub<FrP, 2, 1>(z, fr_limbs(kc.one_abi));
+    g = fe_add<FrP>(g, fe_mul<FrP>(fe_mul<FrP>(zm1, ld_canon(p.l1, i)), fr_limbs(kc.alpha2)));
+    // g: value < 16 r, limbs < 3 * 2^29 + 8
+    st_canon(p.out, i, fe_mul<FrP>(g, zhi));
+  }
+}
+
+static HFr load_fr(const uint64_t v[4]) {
+  HFr r;
+  memcpy(r.l, v, 32);
+  return r;
+}
+static void fill_round_consts(RoundConsts& kc, const HFr& alpha, const HFr& beta, const HFr& gamma,
+                              const uint64_t k[3][4], const uint64_t zh_inv[4][4]) {
+  const host::Field<4>& F = host::FR();
+  memset(&kc, 0, sizeof kc);
+  to_limbs29_shift(kc.beta_k[0], beta, 2);
+  for (int j = 0; j < 3; ++j) to_limbs29_shift(kc.beta_k[j + 1], host::mul(beta, load_fr(k[j]), F), 2);
+  to_limbs29_shift(kc.beta, beta, 2);
+  to_limbs29_shift(kc.gamma, gamma, 1);
+  to_limbs29_shift(kc.alpha, alpha, 1);
+  to_limbs29_shift(kc.alpha2, host::mul(alpha, alpha, F), 2);
+  to_limbs29_shift(kc.one_abi, host::one(F), 0);
+  if (zh_inv)
+    for (int j = 0; j < 4; ++j) to_limbs29_shift(kc.zh_inv[j], load_fr(zh_inv[j]), 1);
+}
+static unsigned grid_for(const pm_ctx* ctx, size_t n) {
+  return (unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cus * 16);
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" int pm_fr_powers_dev(pm_ctx* ctx, const uint64_t base[4], const uint64_t scale[4], size_t n, void* d_out,
+                                void* hip_stream) {
+  if (!ctx || !base || !scale) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n == 0) return PM_OK;
+  if (!d_out) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  const unsigned blocks = grid_for(ctx, n);
+  const u64 T = (u64)blocks * 256;
+  NttConsts c;
+  memset(&c, 0, sizeof c);
+  const HFr b = load_fr(base);
+  to_limbs29_shift(c.w8[0], b, 1);
+  to_limbs29_shift(c.w8[1], hfr_pow_u64(b, T), 1);
+  to_limbs29_shift(c.scale, load_fr(scale), 1);
+  to_limbs29_shift(c.one, host::one(host::FR()), 0);
+  ProfScope prof(ctx, st, "fr_powers");
+  hipLaunchKernelGGL(powers_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)d_out, n, c);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
+}
+
+extern "C" int pm_fr_lincomb_dev(pm_ctx* ctx, uint32_t k, const void* const* d_vecs, const uint64_t* coeffs, size_t n,
+                                 void* d_out, void* hip_stream) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (k == 0 || k > PM_LINCOMB_MAX) return set_err(ctx, PM_ERR_BAD_ARG, "k must be in 1..PM_LINCOMB_MAX");
+  if (n == 0) return PM_OK;
+  if (!d_vecs || !coeffs || !d_out) return set_err(ctx, PM_ERR_BAD_ARG, "null pointer");
+  LincombArgs a;
+  memset(&a, 0, sizeof a);
+  a.k = k;
+  for (uint32_t j = 0; j < k; ++j) {
+    if (!d_vecs[j]) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+    a.v[j] = (const u32x4*)d_vecs[j];
+    to_limbs29_shift(a.c[j], load_fr(coeffs + 4 * j), 1);
+  }
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  ProfScope prof(ctx, st, "fr_lincomb");
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, st, a, (u32x4*)d_out, n);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
+}
+
+extern "C" int pm_plonk_perm_terms_dev(pm_ctx* ctx, const pm_plonk_perm_args* args, size_t n, void* d_num,
+                                       void* d_den, void* hip_stream) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!args) return set_err(ctx, PM_ERR_BAD_ARG, "null args");
+  if (n == 0) return PM_OK;
+  PermPtrs p;
+  for (int j = 0; j < 4; ++j) {
+    p.w[j] = (const u32x4*)args->wires[j];
+    p.s[j] = (const u32x4*)args->sigmas[j];
+    if (!p.w[j] || !p.s[j]) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  }
+  p.roots = (const u32x4*)args->roots;
+  p.num = (u32x4*)d_num;
+  p.den = (u32x4*)d_den;
+  if (!p.roots || !p.num || !p.den) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  RoundConsts kc;
+  fill_round_consts(kc, host::zero<4>(), load_fr(args->beta), load_fr(args->gamma), args->k, nullptr);
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  ProfScope prof(ctx, st, "plonk_perm_terms");
+  hipLaunchKernelGGL(perm_terms_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, st, p, kc, n);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
+}
+
+extern "C" int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, void* d_out,
+                                     void* hip_stream) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!args) return set_err(ctx, PM_ERR_BAD_ARG, "null args");
+  if (n == 0) return PM_OK;
+  if (n & (n - 1)) return set_err(ctx, PM_ERR_LENGTH, "n must be a power of two");
+  QuotPtrs p;
+  for (int j = 0; j < 4; ++j) {
+    p.w[j] = (const u32x4*)args->wires[j];
+    p.s[j] = (const u32x4*)args->sigmas[j];
+  }
+  p.z = (const u32x4*)args->z;
+  p.q_m = (const u32x4*)args->q_m;
+  p.q_l = (const u32x4*)args->q_l;
+  p.q_r = (const u32x4*)args->q_r;
+  p.q_o = (const u32x4*)args->q_o;
+  p.q_4 = (const u32x4*)args->q_4;
+  p.q_c = (const u32x4*)args->q_c;
+  p.pi = (const u32x4*)args->pi;
+  p.l1 = (const u32x4*)args->l1;
+  p.x = (const u32x4*)args->x;
+  p.out = (u32x4*)d_out;
+  const void* all[] = {p.w[0], p.w[1], p.w[2], p.w[3], p.s[0], p.s[1], p.s[2], p.s[3], p.z,  p.q_m,
+                       p.q_l,  p.q_r,  p.q_o,  p.q_4,  p.q_c,  p.pi,   p.l1,   p.x,    p.out};
+  for (const void* q : all)
+    if (!q) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  RoundConsts kc;
+  fill_round_consts(kc, load_fr(args->alpha), load_fr(args->beta), load_fr(args->gamma), args->k, args->zh_inv);
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  ProfScope prof(ctx, st, "plonk_quotient");
+  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, 4 * n);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
+}

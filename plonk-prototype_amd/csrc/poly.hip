@@ -14,27 +14,11 @@
 #include "context.h"
 #include "host_field.h"
 #include "ntt_kernels.cuh"
+#include "poly_common.cuh"
 
 namespace pm {
 
 using host::HFr;
-
-// value * 2^5 for a normalised value < 2r: turns the device product a*b/2^261 into the ABI
-// product a*b/2^256.  Output limbs normalised, value < 64 r.
-PM_DEV Fr fr_shl5(const Fr& t) {
-  constexpr u32 MASK = Consts<FrP>::MASK;
-  Fr r;
-  r.l[0] = (t.l[0] << 5) & MASK;
-#pragma unroll
-  for (int i = 1; i < 8; ++i) r.l[i] = ((t.l[i] << 5) & MASK) | (t.l[i - 1] >> 24);
-  r.l[8] = (t.l[8] << 5) | (t.l[7] >> 24);
-  return r;
-}
-// product of two ABI-form values, ABI form, value < r + r/2^16
-PM_DEV Fr fr_abi_mul(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fr_shl5(fe_mul<FrP>(a, b))); }
-
-PM_DEV Fr ld_canon(const u32x4* p, size_t i) { return fe_load<FrP>(p + 2 * i); }
-PM_DEV void st_canon(u32x4* p, size_t i, const Fr& v) { fe_store<FrP>(p + 2 * i, v); }
 
 // ------------------------------------------------------------------ coefficient-wise ops
 template <int OP>
@@ -393,19 +377,6 @@ __global__ void __launch_bounds__(256) prefix_prod_final_kernel(const u32x4* tmp
 }
 
 // ------------------------------------------------------------------ host helpers
-static void to_limbs29(u32* dst, HFr v) {  // ABI Montgomery -> device Montgomery limbs
-  for (int i = 0; i < 5; ++i) v = host::add(v, v, host::FR());
-  for (int i = 0; i < 9; ++i) {
-    const int lo = 29 * i, j = lo / 64, sh = lo % 64;
-    u64 x = v.l[j] >> sh;
-    if (sh + 29 > 64 && j + 1 < 4) x |= v.l[j + 1] << (64 - sh);
-    dst[i] = (u32)(x & ((1u << 29) - 1));
-  }
-}
-static HFr hfr_pow_u64(HFr b, u64 e) {
-  host::u64 ee[1] = {(host::u64)e};
-  return host::pow(b, ee, 1, host::FR());
-}
 static int build_pow(pm_ctx* ctx, void** out, const HFr& base, u32 count, u32 stride, hipStream_t st) {
   PM_HIP(ctx, hipMalloc(out, (size_t)count * 48));
   NttConsts c;

@@ -118,6 +118,46 @@ class Context:
             C.c_void_p(d_out), out_stride if out_stride is not None else n, log_n, batch, flags,
             C.c_void_p(stream)))
 
+    # ---- device-pointer forms of the polynomial helpers (ints; used by prover.py) -------
+    def fr_powers(self, base, scale, n: int, d_out: int):
+        """out[i] = scale * base^i."""
+        b, sc = (np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (base, scale))
+        self._check(self._lib.pm_fr_powers_dev(self._h, _p(b), _p(sc), n, C.c_void_p(d_out), None))
+
+    def fr_lincomb(self, d_vecs, coeffs, n: int, d_out: int):
+        """out = sum_j coeffs[j] * vecs[j]."""
+        k = len(d_vecs)
+        ptrs = (C.c_void_p * k)(*[C.c_void_p(int(v)) for v in d_vecs])
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(k, 4)
+        self._check(self._lib.pm_fr_lincomb_dev(self._h, k, ptrs, _p(c), n, C.c_void_p(d_out), None))
+
+    def fr_vec_op(self, op: int, d_a: int, d_b: int, b_len: int, d_out: int, n: int):
+        self._check(self._lib.pm_fr_vec_op_dev(self._h, op, C.c_void_p(d_a), C.c_void_p(d_b), b_len,
+                                               C.c_void_p(d_out), n, None))
+
+    def fr_evaluate(self, d_coeffs: int, n: int, point) -> np.ndarray:
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+        out = np.zeros(4, np.uint64)
+        self._check(self._lib.pm_fr_poly_evaluate_dev(self._h, C.c_void_p(d_coeffs), n, _p(pt), _p(out), None))
+        return out
+
+    def fr_ruffini(self, d_coeffs: int, n: int, z, d_out: int):
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
+        self._check(self._lib.pm_fr_poly_ruffini_dev(self._h, C.c_void_p(d_coeffs), n, _p(zz), C.c_void_p(d_out), None))
+
+    def fr_prefix_product(self, d_in: int, n: int, d_out: int):
+        self._check(self._lib.pm_fr_prefix_product_dev(self._h, C.c_void_p(d_in), n, C.c_void_p(d_out), None))
+
+    def fr_batch_inverse(self, d_inout: int, n: int):
+        self._check(self._lib.pm_fr_batch_inverse_dev(self._h, C.c_void_p(d_inout), n, None))
+
+    def plonk_perm_terms(self, args: "_lib.PermArgs", n: int, d_num: int, d_den: int):
+        self._check(self._lib.pm_plonk_perm_terms_dev(self._h, C.byref(args), n, C.c_void_p(d_num),
+                                                      C.c_void_p(d_den), None))
+
+    def plonk_quotient(self, args: "_lib.QuotientArgs", n: int, d_out: int):
+        self._check(self._lib.pm_plonk_quotient_dev(self._h, C.byref(args), n, C.c_void_p(d_out), None))
+
     def field_op(self, op: int, a, b) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.uint64)
         b = np.ascontiguousarray(b, dtype=np.uint64)
@@ -156,6 +196,15 @@ class DeviceVector:
                                                           self.n * 32))
         return out
 
+    def view(self, offset: int, n: int) -> "DeviceVector":
+        """Non-owning window [offset, offset + n) of this vector (keeps the parent alive)."""
+        if offset < 0 or offset + n > self.n:
+            raise ValueError("view out of range")
+        v = object.__new__(_DeviceView)
+        v.ctx, v.n, v._parent = self.ctx, n, self
+        v._p = C.c_void_p(self.ptr + 32 * offset)
+        return v
+
     def free(self):
         if getattr(self, "_p", None) and self.ctx._h:
             self.ctx._lib.pm_dev_free(self.ctx._h, self._p)
@@ -166,6 +215,12 @@ class DeviceVector:
             self.free()
         except Exception:
             pass
+
+
+class _DeviceView(DeviceVector):
+    def free(self):
+        self._p = None
+        self._parent = None
 
 
 class Polynomial:

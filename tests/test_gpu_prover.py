@@ -1,0 +1,268 @@
+"""GPU parity of the prover-round kernels and of the five-round pipeline (SURVEY.md section 8f rows
+N1 / N2, BASELINE.json configs[3]) against oracle/plonk_rounds_oracle.py -- bit-exact -- plus
+oracle-independent checks: the verifier's scalar identity, and the KZG opening equations in the
+exponent with a trapdoor SRS."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bigint_oracle as B
+from oracle import plonk_rounds_oracle as PO
+from oracle.cpu_oracle import ints_to_limbs, limbs_to_ints
+
+pytestmark = pytest.mark.gpu
+R = B.R_MOD
+TAU = 0x2B7E151628AED2A6ABF7158809CF4F3C762E7160F38B4DA56A784D9045190CFE % R
+
+
+def _to_dev(pa, ctx, oracle, vals):
+    return pa.DeviceVector.from_host(ctx, oracle.fr_to_mont(ints_to_limbs(vals, 4)))
+
+
+def _ints(oracle, limbs):
+    return limbs_to_ints(oracle.fr_from_mont(np.ascontiguousarray(limbs).reshape(-1, 4)))
+
+
+def _mont(oracle, v):
+    return oracle.fr_to_mont(ints_to_limbs([v % R], 4))[0]
+
+
+def _rand(rng, n):
+    return [rng.randrange(R) for _ in range(n)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 4097, 70001])
+def test_powers(ctx, oracle, n):
+    import plonk_prototype_amd as pa
+    rng = random.Random(n)
+    base, scale = rng.randrange(R), rng.randrange(R)
+    out = pa.DeviceVector(ctx, n)
+    ctx.fr_powers(_mont(oracle, base), _mont(oracle, scale), n, out.ptr)
+    assert _ints(oracle, out.to_host()) == PO.powers(base, scale, n)
+
+
+def test_powers_gives_the_domain(ctx, oracle):
+    import plonk_prototype_amd as pa
+    dom = pa.EvaluationDomain(1 << 12, ctx)
+    out = pa.DeviceVector(ctx, 1 << 12)
+    ctx.fr_powers(dom.group_gen, _mont(oracle, 1), 1 << 12, out.ptr)
+    assert np.array_equal(out.to_host(), dom.elements())
+
+
+@pytest.mark.parametrize("k,n", [(1, 100), (2, 1), (8, 1000), (16, 5000)])
+def test_lincomb(ctx, oracle, k, n):
+    import plonk_prototype_amd as pa
+    rng = random.Random(100 * k + n)
+    vecs = [_rand(rng, n) for _ in range(k)]
+    coeffs = _rand(rng, k)
+    if k > 2:
+        coeffs[1], coeffs[2] = 0, R - 1
+    dv = [_to_dev(pa, ctx, oracle, v) for v in vecs]
+    out = pa.DeviceVector(ctx, n)
+    ctx.fr_lincomb([d.ptr for d in dv], oracle.fr_to_mont(ints_to_limbs(coeffs, 4)), n, out.ptr)
+    assert _ints(oracle, out.to_host()) == PO.lincomb(coeffs, vecs)
+
+
+def test_lincomb_rejects_bad_k(ctx):
+    import plonk_prototype_amd as pa
+    v = pa.DeviceVector(ctx, 4)
+    with pytest.raises(pa.Error) as e:
+        ctx.fr_lincomb([v.ptr] * 17, np.zeros((17, 4), np.uint64), 4, v.ptr)
+    assert e.value.code == -1
+
+
+def _perm_args(pa, oracle, wires, sigmas, roots, beta, gamma):
+    from plonk_prototype_amd import _lib
+    a = _lib.PermArgs()
+    for j in range(4):
+        a.wires[j], a.sigmas[j] = wires[j].ptr, sigmas[j].ptr
+    a.roots = roots.ptr
+    u = lambda v: (pa.prover.C.c_uint64 * 4)(*[int(x) for x in _mont(oracle, v)])   # noqa: E731
+    a.beta, a.gamma = u(beta), u(gamma)
+    for j, k in enumerate((7, 13, 17)):
+        a.k[j] = u(k)
+    return a
+
+
+@pytest.mark.parametrize("n", [1, 300, 8192])
+def test_perm_terms(ctx, oracle, n):
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover  # noqa: F401
+    rng = random.Random(n)
+    wires, sigmas, roots = [_rand(rng, n) for _ in range(4)], [_rand(rng, n) for _ in range(4)], _rand(rng, n)
+    wires[0][0], sigmas[1][0] = 0, R - 1
+    beta, gamma = rng.randrange(R), rng.randrange(R)
+    dw, ds = [_to_dev(pa, ctx, oracle, v) for v in wires], [_to_dev(pa, ctx, oracle, v) for v in sigmas]
+    dr = _to_dev(pa, ctx, oracle, roots)
+    num, den = pa.DeviceVector(ctx, n), pa.DeviceVector(ctx, n)
+    ctx.plonk_perm_terms(_perm_args(pa, oracle, dw, ds, dr, beta, gamma), n, num.ptr, den.ptr)
+    en, ed = PO.perm_terms(wires, sigmas, roots, beta, gamma)
+    assert _ints(oracle, num.to_host()) == en
+    assert _ints(oracle, den.to_host()) == ed
+
+
+@pytest.mark.parametrize("n", [4, 64, 1024])
+def test_quotient_kernel(ctx, oracle, n):
+    """Random (unsatisfied) inputs on the true 4n coset: the kernel is a pointwise map, so parity needs
+    no valid circuit."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd import _lib
+    rng = random.Random(n)
+    n4 = 4 * n
+    names = ["w0", "w1", "w2", "w3", "z", "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "pi", "s0", "s1", "s2", "s3", "l1"]
+    v = {k: _rand(rng, n4) for k in names}
+    v["q_m"][0], v["z"][1], v["w0"][2] = 0, 1, R - 1
+    x = PO.powers(B.Domain(n4).group_gen, 7, n4)
+    alpha, beta, gamma = (rng.randrange(R) for _ in range(3))
+    d = {k: _to_dev(pa, ctx, oracle, val) for k, val in v.items()}
+    dx = _to_dev(pa, ctx, oracle, x)
+    qa = _lib.QuotientArgs()
+    u = lambda s: (PR.C.c_uint64 * 4)(*[int(t) for t in _mont(oracle, s)])   # noqa: E731
+    for j in range(4):
+        qa.wires[j], qa.sigmas[j] = d[f"w{j}"].ptr, d[f"s{j}"].ptr
+    for k in ("z", "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "pi", "l1"):
+        setattr(qa, k, d[k].ptr)
+    qa.x = dx.ptr
+    qa.alpha, qa.beta, qa.gamma = u(alpha), u(beta), u(gamma)
+    for j, k in enumerate((7, 13, 17)):
+        qa.k[j] = u(k)
+    for j in range(4):
+        qa.zh_inv[j] = u(PO.inv(pow(x[j], n, R) - 1))
+    out = pa.DeviceVector(ctx, n4)
+    ctx.plonk_quotient(qa, n, out.ptr)
+    exp = PO.quotient_evals(n, [v[f"w{j}"] for j in range(4)], v["z"],
+                            {k: v[k] for k in ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")}, v["pi"],
+                            [v[f"s{j}"] for j in range(4)], v["l1"], x, alpha, beta, gamma)
+    assert _ints(oracle, out.to_host()) == exp
+
+
+def _srs(oracle, n):
+    G = oracle.g1_generator()
+    out = np.zeros((n, 12), np.uint64)
+    t = 1
+    for i in range(n):
+        out[i] = oracle.g1_mul(G, ints_to_limbs([t], 4)[0])
+        t = t * TAU % R
+    return out
+
+
+def _g(oracle, k):
+    return oracle.g1_mul(oracle.g1_generator(), ints_to_limbs([k % R], 4)[0])
+
+
+def _setup(ctx, oracle, n, seed):
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd.field import fr_vec_from_limbs
+    from plonk_prototype_amd.synthetic import chain_circuit
+    circuit, wit, pi = chain_circuit(n, seed)
+    srs = _srs(oracle, n)
+    ck = pa.CommitKey(srs, ctx, precompute=(n >= 64))
+    pk = pa.prover.preprocess(circuit, ctx)
+    sel = {k: fr_vec_from_limbs(getattr(circuit, k)) for k in ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")}
+    ints = (sel, circuit.sigma_index.tolist(), [fr_vec_from_limbs(wit[j]) for j in range(4)], fr_vec_from_limbs(pi))
+    return circuit, wit, pi, srs, ck, pk, ints
+
+
+@pytest.mark.parametrize("n", [4, 16, 256])
+def test_prove_matches_the_oracle(ctx, oracle, n):
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    circuit, wit, pi, srs, ck, pk, (sel, sigma, wi, pii) = _setup(ctx, oracle, n, seed=n)
+    proof = PR.prove(pk, ck, wit, pi)
+    exp = PO.prove(n, sel, sigma, wi, pii, proof.challenges)
+    # openings
+    got = {k: _ints(oracle, v)[0] for k, v in proof.evaluations.items()}
+    assert got == exp["evals"]
+    # commitments: the oracle's Pippenger over the oracle's coefficient vectors
+    def commit(c):
+        return oracle.g1_msm(srs[:len(c)], oracle.fr_to_mont(ints_to_limbs(c, 4)))
+    want = {nm: commit(exp["wire_coeffs"][j]) for j, nm in enumerate("abcd")}
+    want["z"] = commit(exp["z_coeffs"])
+    for i in range(4):
+        want[f"t_{i + 1}"] = commit(exp["t_coeffs"][i * n:(i + 1) * n])
+    want["w_z"], want["w_zw"] = commit(exp["w_z"]), commit(exp["w_zw"])
+    assert set(want) == set(proof.commitments)
+    for k in want:
+        assert np.array_equal(proof.commitments[k], want[k]), k
+    # oracle-independent: the verifier's scalar identity ...
+    pi_z = B.horner(B.ifft(pii, n.bit_length() - 1), proof.challenges["z"])
+    assert PR.check_identity(proof, n, pi_z)
+    # ... and both KZG opening equations in the exponent (tau is known to the test):
+    #   W(tau) (tau - z) = F(tau) - F(z)   with commitments checked as  [p(tau)] G
+    ch, ev = proof.challenges, got
+    zz, v = ch["z"], ch["v"]
+    zn = pow(zz, n, R)
+    agg_eval = (ev["t"] + v * ev["r"] + v ** 2 * ev["a"] + v ** 3 * ev["b"] + v ** 4 * ev["c"] + v ** 5 * ev["d"]
+                + v ** 6 * ev["sigma_1"] + v ** 7 * ev["sigma_2"] + v ** 8 * ev["sigma_3"]) % R
+    tau_of = lambda c: B.horner(c, TAU)   # noqa: E731
+    parts = [exp["t_coeffs"][i * n:(i + 1) * n] for i in range(4)]
+    agg_tau = (sum(pow(zn, i, R) * tau_of(parts[i]) for i in range(4)) + v * tau_of(exp["r_coeffs"])
+               + sum(pow(v, 2 + j, R) * tau_of(exp["wire_coeffs"][j]) for j in range(4))) % R
+    sig_c = [B.ifft([PO.K[p // n] * pow(B.Domain(n).group_gen, p % n, R) % R for p in sigma[j]], n.bit_length() - 1)
+             for j in range(3)]
+    agg_tau = (agg_tau + sum(pow(v, 6 + j, R) * tau_of(sig_c[j]) for j in range(3))) % R
+    assert np.array_equal(proof.commitments["w_z"], _g(oracle, (agg_tau - agg_eval) * PO.inv(TAU - zz)))
+    zw = zz * B.Domain(n).group_gen % R
+    assert np.array_equal(proof.commitments["w_zw"],
+                          _g(oracle, (tau_of(exp["z_coeffs"]) - ev["z_next"]) * PO.inv(TAU - zw)))
+
+
+def test_prove_is_deterministic_and_transcript_bound(ctx, oracle):
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.transcript import Transcript
+    n = 64
+    circuit, wit, pi, srs, ck, pk, _ = _setup(ctx, oracle, n, seed=9)
+    p1, p2 = PR.prove(pk, ck, wit, pi), PR.prove(pk, ck, wit, pi)
+    assert p1.challenges == p2.challenges
+    assert all(np.array_equal(p1.commitments[k], p2.commitments[k]) for k in p1.commitments)
+    p3 = PR.prove(pk, ck, wit, pi, transcript=Transcript(b"another protocol"))
+    assert p3.challenges["beta"] != p1.challenges["beta"]
+    assert np.array_equal(p3.commitments["a"], p1.commitments["a"])          # round 1 has no challenge
+    assert not np.array_equal(p3.commitments["z"], p1.commitments["z"])
+
+
+def test_tampered_witness_fails_the_identity(ctx, oracle):
+    import plonk_prototype_amd.prover as PR
+    n = 64
+    circuit, wit, pi, srs, ck, pk, (sel, sigma, wi, pii) = _setup(ctx, oracle, n, seed=4)
+    bad = wit.copy()
+    bad[2, 7] = bad[2, 8]
+    proof = PR.prove(pk, ck, bad, pi)
+    pi_z = B.horner(B.ifft(pii, 6), proof.challenges["z"])
+    assert not PR.check_identity(proof, n, pi_z)
+    good = PR.prove(pk, ck, wit, pi)
+    assert PR.check_identity(good, n, B.horner(B.ifft(pii, 6), good.challenges["z"]))
+
+
+def test_prover_key_rejects_bad_circuits(ctx, oracle):
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.synthetic import chain_circuit
+    circuit, wit, pi = chain_circuit(16, 1)
+    circuit.sigma_index = circuit.sigma_index.copy()
+    circuit.sigma_index[0, 0] = circuit.sigma_index[0, 1]                      # not a permutation
+    with pytest.raises(ValueError):
+        PR.preprocess(circuit, ctx)
+
+
+def test_prove_2_16_gates(ctx, oracle):
+    """A mid-size run (4n = 2^18 coset): scalar identity, and commitments against the known discrete
+    logs of an arithmetic-progression SRS (no 2^16 scalar multiplications on the CPU)."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.synthetic import chain_circuit
+    n = 1 << 16
+    circuit, wit, pi = chain_circuit(n, 11)
+    k0, d = ints_to_limbs([0x1234567], 4)[0], ints_to_limbs([0x9E3779B9], 4)[0]
+    srs = oracle.g1_bases_arith(k0, d, n, threads=8)
+    ck = pa.CommitKey(srs, ctx, precompute=True)
+    pk = PR.preprocess(circuit, ctx)
+    proof = PR.prove(pk, ck, wit, pi)
+    pi_coeffs = oracle.fr_ntt(pi, 16, 1)
+    pi_z = _ints(oracle, oracle.fr_poly_evaluate(pi_coeffs, _mont(oracle, proof.challenges["z"])))[0]
+    assert PR.check_identity(proof, n, pi_z)
+    # commitment to wire a: sum_i a_i (k0 + i d) G
+    a_coeffs = oracle.fr_ntt(wit[0], 16, 1)
+    dlog = oracle.expected_dlog(a_coeffs, 0, k0, d)
+    assert np.array_equal(proof.commitments["a"], oracle.g1_mul(oracle.g1_generator(), dlog))

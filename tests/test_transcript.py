@@ -1,0 +1,69 @@
+"""CPU: the Fiat-Shamir transcript (plonk-prototype_amd/transcript.py).
+Pins: the Keccak permutation against hashlib's SHA3-256, and Merlin's published known-answer vector
+("test protocol" / "some label" / "some data" -> 32 challenge bytes)."""
+import hashlib
+
+import numpy as np
+
+from oracle import bigint_oracle as B
+from plonk_prototype_amd import transcript as T
+from plonk_prototype_amd.field import R_MOD, fr_to_limbs
+
+
+def _sha3_256(msg: bytes) -> bytes:
+    st, rate = bytearray(200), 136
+    m = bytearray(msg) + b"\x06"
+    m += bytes(-len(m) % rate)
+    m[-1] |= 0x80
+    for off in range(0, len(m), rate):
+        for i in range(rate):
+            st[i] ^= m[off + i]
+        T.keccak_f1600(st)
+    return bytes(st[:32])
+
+
+def test_keccak_permutation_matches_hashlib():
+    for msg in (b"", b"abc", bytes(range(256)) * 3, b"\xff" * 135, b"\x00" * 136):
+        assert _sha3_256(msg) == hashlib.sha3_256(msg).digest()
+
+
+def test_merlin_known_answer():
+    t = T.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == \
+        "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_transcript_is_order_and_content_sensitive():
+    def run(msgs):
+        t = T.Transcript(b"plonk")
+        for lab, m in msgs:
+            t.append_message(lab, m)
+        return t.challenge_scalar(b"beta")
+    base = run([(b"a", b"1"), (b"b", b"2")])
+    assert base == run([(b"a", b"1"), (b"b", b"2")])
+    assert base != run([(b"b", b"2"), (b"a", b"1")])
+    assert base != run([(b"a", b"1"), (b"b", b"3")])
+    assert base != run([(b"a", b"1b"), (b"", b"2")])
+    assert 0 <= base < R_MOD
+    # long messages cross the 166-byte STROBE rate
+    assert run([(b"x", bytes(1000))]) != run([(b"x", bytes(1001))])
+
+
+def test_successive_challenges_differ_and_chain():
+    t = T.Transcript(b"plonk")
+    t.append_scalar(b"s", fr_to_limbs(5))
+    c1, c2 = t.challenge_scalar(b"c"), t.challenge_scalar(b"c")
+    assert c1 != c2
+
+
+def test_g1_compress_matches_the_oracle_encoding(oracle):
+    from oracle.cpu_oracle import ints_to_limbs, limbs_to_ints
+    G = oracle.g1_generator()
+    for k in (1, 2, 3, 0xDEADBEEF, R_MOD - 1):
+        xy = oracle.g1_mul(G, ints_to_limbs([k], 4)[0])
+        can = limbs_to_ints(oracle.fp_from_mont(xy.reshape(2, 6)))
+        assert T.g1_compress(xy) == B.g1_compress((can[0], can[1]))
+    assert T.g1_compress(np.zeros(12, np.uint64)) == B.g1_compress(None)
+    # the generator's compressed encoding starts 0x97f1d3a7... (zcash / dusk_bls12_381 docs)
+    assert T.g1_compress(G).hex().startswith("97f1d3a73197d794")
