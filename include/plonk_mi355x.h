@@ -231,6 +231,10 @@ typedef struct pm_plonk_quotient_args {
 int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, void* d_out,
                           void* hip_stream);
 
+/* Keccak-f[1600] on a 200-byte state (host; the permutation under the Merlin / STROBE-128 transcript
+ * the prover derives its challenges from -- merlin is a dependency of dusk-plonk, ref:Cargo.toml:19). */
+void pm_keccak_f1600(uint8_t state[200]);
+
 /* ---- introspection / tuning (not needed by the prover) --------------------------------- */
 
 /* Number of kernel launches and the Stockham radices the library will use for 2^log_n. */

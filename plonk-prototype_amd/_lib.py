@@ -70,6 +70,7 @@ SIGNATURES = {
     "pm_plonk_perm_terms_dev": (C.c_int, [C.c_void_p, C.POINTER(PermArgs), C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "pm_plonk_quotient_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientArgs), C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pm_keccak_f1600": (None, [C.c_char_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     "pm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

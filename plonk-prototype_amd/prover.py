@@ -117,6 +117,18 @@ class ProverKey:
         i4 = pow(fr_from_limbs(omega4), n, R_MOD)
         self.zh_inv = [fr_to_limbs(pow((gn * pow(i4, k, R_MOD) - 1) % R_MOD, -1, R_MOD)) for k in range(4)]
 
+    def workspace(self, name: str, n: int) -> DeviceVector:
+        """Per-proof scratch, allocated on the first proof and reused by later ones (a prover
+        service proves many witnesses against one key; hipMalloc/hipFree of GB-sized buffers
+        would otherwise sit inside every proof)."""
+        ws = self.__dict__.setdefault("_ws", {})
+        v = ws.get(name)
+        if v is None or v.n != n:
+            if v is not None:
+                v.free()
+            v = ws[name] = DeviceVector(self.ctx, n)
+        return v
+
     def selector_coeffs(self, name: str) -> int:
         return self.sel_coeffs.ptr + 32 * self.n * SELECTORS.index(name)
 
@@ -135,20 +147,25 @@ def _commit_batch(ck: CommitKey, d_ptr: int, n: int, batch: int, stride: int) ->
 
 def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript: Transcript | None = None) -> Proof:
     """witness: [4, n, 4] wire values (a, b, c, d rows) in Montgomery limbs; public_inputs: [n, 4]
-    evaluations of PI on H (None = no public inputs)."""
+    evaluations of PI on H (None = no public inputs).  Either may be a DeviceVector already in HBM."""
     ctx, n, log_n = pk.ctx, pk.n, pk.log_n
     if ck.max_degree() + 1 < n:
         raise ValueError("commit key shorter than the circuit")
-    w = np.ascontiguousarray(witness, dtype=np.uint64).reshape(4 * n, 4)
     ts = transcript or Transcript(b"plonk")
     ts.circuit_domain_sep(n)
     proof = Proof()
     fr = fr_to_limbs
 
     # ---- round 1: wire polynomials ----------------------------------------------------------------
-    wire_evals = DeviceVector.from_host(ctx, w)
+    if isinstance(witness, DeviceVector):                          # already resident: [a | b | c | d], 4n elements
+        if witness.n != 4 * n:
+            raise ValueError("device witness must hold 4n elements")
+        wire_evals, own_witness = witness, False
+    else:
+        wire_evals = DeviceVector.from_host(ctx, np.ascontiguousarray(witness, dtype=np.uint64).reshape(4 * n, 4))
+        own_witness = True
     # coefficient buffer [a, b, c, d, z, pi], each n long
-    coeffs = DeviceVector(ctx, 6 * n)
+    coeffs = pk.workspace("coeffs", 6 * n)
     ctx.fr_ntt_dev(wire_evals.ptr, n, coeffs.ptr, log_n, _lib.NTT_INVERSE, batch=4)
     for name, c in zip(("a", "b", "c", "d"), _commit_batch(ck, coeffs.ptr, n, 4, n)):
         proof.commitments[name] = c
@@ -156,7 +173,7 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
 
     # ---- round 2: permutation grand product --------------------------------------------------------
     beta, gamma = ts.challenge_scalar(b"beta"), ts.challenge_scalar(b"gamma")
-    num, den = DeviceVector(ctx, n), DeviceVector(ctx, n)
+    num, den = pk.workspace("num", n), pk.workspace("den", n)
     pa = _lib.PermArgs()
     for j in range(4):
         pa.wires[j] = wire_evals.ptr + 32 * j * n
@@ -177,13 +194,14 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
     # ---- round 3: quotient ---------------------------------------------------------------------------
     alpha = ts.challenge_scalar(b"alpha")
     pi_coeffs = coeffs.ptr + 32 * 5 * n
-    if public_inputs is None:
-        pi_host = np.zeros((n, 4), np.uint64)
+    if isinstance(public_inputs, DeviceVector):
+        pi_ev, own_pi = public_inputs, False
     else:
-        pi_host = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(n, 4)
-    pi_ev = DeviceVector.from_host(ctx, pi_host)
+        pi_host = np.zeros((n, 4), np.uint64) if public_inputs is None else \
+            np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(n, 4)
+        pi_ev, own_pi = DeviceVector.from_host(ctx, pi_host), True
     ctx.fr_ntt_dev(pi_ev.ptr, n, pi_coeffs, log_n, _lib.NTT_INVERSE)
-    coset = DeviceVector(ctx, 6 * 4 * n)                           # a, b, c, d, z, pi on the 4n coset
+    coset = pk.workspace("coset", 6 * 4 * n)                         # a, b, c, d, z, pi on the 4n coset
     ctx.fr_ntt_dev(coeffs.ptr, n, coset.ptr, log_n + 2, _lib.NTT_COSET, batch=6, in_stride=n, out_stride=4 * n)
     qa = _lib.QuotientArgs()
     for j in range(4):
@@ -199,7 +217,7 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
         qa.k[j] = _arr4(pk.k[j])
     for j in range(4):
         qa.zh_inv[j] = _arr4(pk.zh_inv[j])
-    t = DeviceVector(ctx, 4 * n)
+    t = pk.workspace("t", 4 * n)
     ctx.plonk_quotient(qa, n, t.ptr)
     ctx.fr_ntt_dev(t.ptr, 4 * n, t.ptr, log_n + 2, _lib.NTT_INVERSE | _lib.NTT_COSET)
     for i, c in enumerate(_commit_batch(ck, t.ptr, n, 4, n)):
@@ -234,7 +252,7 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
     vec_ptrs += [z_coeffs, pk.sigma_coeffs.ptr + 32 * 3 * n]
     lin_coeffs += [(alpha * ident + alpha * alpha % R_MOD * l1_z) % R_MOD,
                    (-alpha * copy3 % R_MOD * beta % R_MOD * z_next) % R_MOD]
-    r_poly = DeviceVector(ctx, n)
+    r_poly = pk.workspace("r", n)
     ctx.fr_lincomb(vec_ptrs, np.stack([fr(c) for c in lin_coeffs]), n, r_poly.ptr)
     ev["r"] = ctx.fr_evaluate(r_poly.ptr, n, zc_l)
     for name in ("a", "b", "c", "d", "sigma_1", "sigma_2", "sigma_3", "z_next", "t", "r"):
@@ -246,17 +264,19 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
     agg_ptrs = [t.ptr + 32 * i * n for i in range(4)] + [r_poly.ptr] + [coeffs.ptr + 32 * j * n for j in range(4)] \
         + [pk.sigma_coeffs.ptr + 32 * j * n for j in range(3)]
     agg_coeffs = [1, zn, zn * zn % R_MOD, pow(zn, 3, R_MOD)] + [pow(v, e, R_MOD) for e in range(1, 9)]
-    agg = DeviceVector(ctx, n)
+    agg = pk.workspace("agg", n)
     ctx.fr_lincomb(agg_ptrs, np.stack([fr(c) for c in agg_coeffs]), n, agg.ptr)
-    wit = DeviceVector(ctx, 2 * n)                                  # [W_z | W_zw], n - 1 coefficients each
+    wit = pk.workspace("wit", 2 * n)                                # [W_z | W_zw], n - 1 coefficients each
     ctx.fr_ruffini(agg.ptr, n, zc_l, wit.ptr)
     ctx.fr_ruffini(z_coeffs, n, zw_l, wit.ptr + 32 * n)
     for name, c in zip(("w_z", "w_zw"), _commit_batch(ck, wit.ptr, n - 1, 2, n)):
         proof.commitments[name] = c
         ts.append_commitment(name.encode(), c)
     proof.challenges = {"beta": beta, "gamma": gamma, "alpha": alpha, "z": zc, "v": v}
-    for dv in (wire_evals, coeffs, num, den, pi_ev, coset, t, r_poly, agg, wit):
-        dv.free()
+    if own_witness:
+        wire_evals.free()
+    if own_pi:
+        pi_ev.free()
     return proof
 
 

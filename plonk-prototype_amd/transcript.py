@@ -15,11 +15,14 @@ pinned (upstream's label strings are not available here).  Host-side, a few hund
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 
 from .field import P_MOD, R_MOD, fp_from_limbs, fr_from_limbs
 
 _MASK = (1 << 64) - 1
+_native = None
 _RC = [
     0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
     0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
@@ -36,7 +39,18 @@ def _rol(x: int, n: int) -> int:
 
 
 def keccak_f1600(state: bytearray) -> None:
-    """In-place Keccak-f[1600] on a 200-byte state (lane (x, y) at byte 8 (x + 5 y), little-endian)."""
+    """In-place Keccak-f[1600] on a 200-byte state: the library's ``pm_keccak_f1600``."""
+    global _native
+    if _native is None:
+        from . import _lib
+        _native = _lib.load().pm_keccak_f1600
+    buf = (ctypes.c_char * 200).from_buffer(state)
+    _native(buf)
+
+
+def keccak_f1600_py(state: bytearray) -> None:
+    """The same permutation in plain Python (lane (x, y) at byte 8 (x + 5 y), little-endian); kept as
+    the cross-check of the native one in tests/test_transcript.py."""
     a = [[int.from_bytes(state[8 * (x + 5 * y):8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
     for rc in _RC:
         c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]

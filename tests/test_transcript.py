@@ -10,7 +10,8 @@ from plonk_prototype_amd import transcript as T
 from plonk_prototype_amd.field import R_MOD, fr_to_limbs
 
 
-def _sha3_256(msg: bytes) -> bytes:
+def _sha3_256(msg: bytes, perm=None) -> bytes:
+    perm = perm or T.keccak_f1600
     st, rate = bytearray(200), 136
     m = bytearray(msg) + b"\x06"
     m += bytes(-len(m) % rate)
@@ -18,13 +19,14 @@ def _sha3_256(msg: bytes) -> bytes:
     for off in range(0, len(m), rate):
         for i in range(rate):
             st[i] ^= m[off + i]
-        T.keccak_f1600(st)
+        perm(st)
     return bytes(st[:32])
 
 
 def test_keccak_permutation_matches_hashlib():
     for msg in (b"", b"abc", bytes(range(256)) * 3, b"\xff" * 135, b"\x00" * 136):
-        assert _sha3_256(msg) == hashlib.sha3_256(msg).digest()
+        assert _sha3_256(msg) == hashlib.sha3_256(msg).digest()                       # pm_keccak_f1600
+        assert _sha3_256(msg, T.keccak_f1600_py) == hashlib.sha3_256(msg).digest()    # plain-Python restatement
 
 
 def test_merlin_known_answer():
