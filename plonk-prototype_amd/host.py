@@ -491,6 +491,14 @@ class CommitKey:
             d.free()
         return np.stack([g1_to_affine(x)[0] for x in xyz])
 
+    def commit_batch_dev(self, d_ptr: int, n: int, batch: int, stride: int | None = None) -> list:
+        """Commit to `batch` device-resident coefficient vectors of n elements (vector j at
+        d_ptr + 32 j stride) -> list of affine [12].  The prover's form of ``commit``."""
+        if n > self._bases.n:
+            raise Error(_lib.PM_ERR_LENGTH, "PolynomialDegreeTooLarge")
+        xyz = self._bases.msm_batch_dev(d_ptr, n, batch, stride=stride)
+        return [g1_to_affine(p)[0] for p in xyz]
+
     def commit(self, coeffs) -> np.ndarray:
         """-> Commitment as affine G1 [12] ((0, 0) for the zero polynomial)."""
         c = _fr(coeffs)

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 from .field import GENERATOR, K1, K2, K3, R_MOD, fr_from_limbs, fr_to_limbs
-from .host import CommitKey, Context, DeviceVector, domain_info, g1_to_affine
+from .host import CommitKey, Context, DeviceVector, domain_info
 from .transcript import Transcript
 
 SELECTORS = ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")
@@ -140,14 +140,18 @@ def preprocess(circuit: Circuit, ctx: Context) -> ProverKey:
     return ProverKey(circuit, ctx)
 
 
-def _commit_batch(ck: CommitKey, d_ptr: int, n: int, batch: int, stride: int) -> list:
-    xyz = ck._bases.msm_batch_dev(d_ptr, n, batch, stride=stride)
-    return [g1_to_affine(p)[0] for p in xyz]
+def _commit_batch(ck, d_ptr: int, n: int, batch: int, stride: int) -> list:
+    # CommitKey on one GPU; dist.ShardedCommitKey when the SRS is split over the ranks of a node
+    return ck.commit_batch_dev(d_ptr, n, batch, stride)
 
 
 def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript: Transcript | None = None) -> Proof:
     """witness: [4, n, 4] wire values (a, b, c, d rows) in Montgomery limbs; public_inputs: [n, 4]
-    evaluations of PI on H (None = no public inputs).  Either may be a DeviceVector already in HBM."""
+    evaluations of PI on H (None = no public inputs).  Either may be a DeviceVector already in HBM.
+
+    Multi-GPU: every rank calls prove() with the same inputs and a ``dist.ShardedCommitKey``; the
+    O(n log n) polynomial work is replicated (13 % of a proof), each of the 11 MSMs is split by
+    coefficient range, and the ranks exchange 144-byte partial points.  All ranks return the same proof."""
     ctx, n, log_n = pk.ctx, pk.n, pk.log_n
     if ck.max_degree() + 1 < n:
         raise ValueError("commit key shorter than the circuit")

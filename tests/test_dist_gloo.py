@@ -45,6 +45,13 @@ def _worker(rank, world, port, n, q):
         else:
             part[6:12] = one
         total = allgather_fold(part)
+        # the batched form the sharded prover uses: k partial points per rank in one all_gather
+        from plonk_prototype_amd.dist import allgather_fold_many
+        ident = np.zeros(18, np.uint64)
+        ident[6:12] = one
+        many = allgather_fold_many(np.stack([part, ident, part]))
+        assert many.shape == (3, 18) and np.array_equal(many[0], total) and np.array_equal(many[2], total)
+        assert not many[1][12:].any()                                  # identity + identity = identity (Z = 0)
         q.put((rank, total.tolist(), o.g1_msm(pts, sc).tolist(), (lo, hi)))
     finally:
         dist.destroy_process_group()
