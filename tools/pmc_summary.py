@@ -1,11 +1,14 @@
 """Summarise rocprofv3 --pmc csv output: per kernel, mean counter value per dispatch.
-usage: python tools/pmc_summary.py gpurun_out/r01 profiles/r01_pmc_summary.json"""
+usage: python tools/pmc_summary.py gpurun_out/r01 profiles/r01_pmc_summary.json [log_n [dir_prefix]]
+dir_prefix (default "pmc_") selects the pass directories; "prv_" = the prover-round passes, for which
+only the summary json is written (no ntt_traffic.json)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 root, out = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(list))
-for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+prefix = sys.argv[4] if len(sys.argv) > 4 else "pmc_"
+for path in glob.glob(os.path.join(root, prefix + "*", "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name") or row.get("Kernel Name")
@@ -39,7 +42,7 @@ for k, v in summary.items():
         traffic[f"msm_accumulate_l1_2^{log_n}"] = int(v["hbm_bytes_per_launch_corrected"])
         if "SQ_INSTS_VALU" in v:
             traffic[f"msm_accumulate_l1_2^{log_n}_valu_insts"] = int(v["SQ_INSTS_VALU"]["mean"])
-if traffic:
+if traffic and prefix == "pmc_":
     json.dump(traffic, open(os.path.join(os.path.dirname(out), "ntt_traffic.json"), "w"), indent=1, sort_keys=True)
     print("traffic:", traffic)
 for k, v in sorted(summary.items()):
