@@ -42,3 +42,8 @@ def fr_vec_from_limbs(a) -> list[int]:
 def fp_from_limbs(a) -> int:
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(6)
     return int.from_bytes(a.tobytes(), "little") * _R384_INV % P_MOD
+
+
+def fp_to_limbs(v: int) -> np.ndarray:
+    m = (v % P_MOD) * ((1 << 384) % P_MOD) % P_MOD
+    return np.frombuffer(m.to_bytes(48, "little"), dtype=np.uint64).copy()

@@ -57,6 +57,33 @@ class Proof:
     evaluations: dict = field(default_factory=dict)
     challenges: dict = field(default_factory=dict)   # ints; recomputable from the transcript
 
+    COMMITMENTS = ("a", "b", "c", "d", "z", "t_1", "t_2", "t_3", "t_4", "w_z", "w_zw")
+    EVALUATIONS = ("a", "b", "c", "d", "sigma_1", "sigma_2", "sigma_3", "z_next", "t", "r")
+
+    def to_bytes(self) -> bytes:
+        """11 x 48-byte compressed G1 then 10 x 32-byte little-endian canonical scalars (the layout of
+        dusk's ``Proof::to_bytes``, which carries 6 more evaluations for the gates not built here)."""
+        from .transcript import g1_compress
+        return b"".join(g1_compress(self.commitments[k]) for k in self.COMMITMENTS) + \
+            b"".join(fr_from_limbs(self.evaluations[k]).to_bytes(32, "little") for k in self.EVALUATIONS)
+
+    @classmethod
+    def from_bytes(cls, data: bytes) -> "Proof":
+        from .transcript import g1_decompress
+        if len(data) != 48 * len(cls.COMMITMENTS) + 32 * len(cls.EVALUATIONS):
+            raise ValueError("wrong proof length")
+        p, off = cls(), 0
+        for k in cls.COMMITMENTS:
+            p.commitments[k] = g1_decompress(data[off:off + 48])
+            off += 48
+        for k in cls.EVALUATIONS:
+            v = int.from_bytes(data[off:off + 32], "little")
+            if v >= R_MOD:
+                raise ValueError("scalar is not reduced")
+            p.evaluations[k] = fr_to_limbs(v)
+            off += 32
+        return p
+
 
 def _arr4(v) -> "C.Array":
     return (C.c_uint64 * 4)(*[int(x) for x in np.asarray(v, dtype=np.uint64).reshape(4)])

@@ -157,6 +157,29 @@ def g1_compress(xy) -> bytes:
     return bytes(out)
 
 
+def g1_decompress(data: bytes) -> np.ndarray:
+    """48-byte zcash compressed encoding -> affine Montgomery limbs [12] (``G1Affine::from_compressed``
+    without the subgroup check).  Raises ValueError for malformed input / x not on the curve."""
+    from .field import fp_to_limbs
+    if len(data) != 48 or not data[0] & 0x80:
+        raise ValueError("not a 48-byte compressed G1 point")
+    inf, big = bool(data[0] & 0x40), bool(data[0] & 0x20)
+    x = int.from_bytes(bytes([data[0] & 0x1F]) + data[1:], "big")
+    if inf:
+        if x or big:
+            raise ValueError("malformed point at infinity")
+        return np.zeros(12, np.uint64)
+    if x >= P_MOD:
+        raise ValueError("x is not reduced")
+    rhs = (pow(x, 3, P_MOD) + 4) % P_MOD
+    y = pow(rhs, (P_MOD + 1) // 4, P_MOD)                 # p = 3 mod 4
+    if y * y % P_MOD != rhs:
+        raise ValueError("x is not on the curve")
+    if (y > (P_MOD - 1) // 2) != big:
+        y = P_MOD - y
+    return np.concatenate([fp_to_limbs(x), fp_to_limbs(y)])
+
+
 class Transcript:
     """``merlin::Transcript`` with dusk-plonk's ``TranscriptProtocol`` methods."""
 

@@ -69,3 +69,41 @@ def test_g1_compress_matches_the_oracle_encoding(oracle):
     assert T.g1_compress(np.zeros(12, np.uint64)) == B.g1_compress(None)
     # the generator's compressed encoding starts 0x97f1d3a7... (zcash / dusk_bls12_381 docs)
     assert T.g1_compress(G).hex().startswith("97f1d3a73197d794")
+
+
+def test_g1_decompress_roundtrip_and_rejects(oracle):
+    from oracle.cpu_oracle import ints_to_limbs
+    G = oracle.g1_generator()
+    for k in (1, 2, 5, 0xC0FFEE, R_MOD - 2):
+        xy = oracle.g1_mul(G, ints_to_limbs([k], 4)[0])
+        assert np.array_equal(T.g1_decompress(T.g1_compress(xy)), xy)
+    assert not T.g1_decompress(bytes([0xC0]) + bytes(47)).any()
+    import pytest
+    from plonk_prototype_amd.field import P_MOD
+    off_curve = next(x for x in range(1, 100) if pow((x ** 3 + 4) % P_MOD, (P_MOD - 1) // 2, P_MOD) != 1)
+    for bad in (bytes(48), bytes([0x80]) + bytes(46) + bytes([off_curve]), bytes([0xE0]) + bytes(47),
+                bytes([0x9F]) + b"\xff" * 47, bytes(47)):
+        with pytest.raises(ValueError):
+            T.g1_decompress(bad)
+
+
+def test_proof_serialisation_roundtrip(oracle):
+    from oracle.cpu_oracle import ints_to_limbs
+    from plonk_prototype_amd.prover import Proof
+    G = oracle.g1_generator()
+    p = Proof()
+    for i, k in enumerate(Proof.COMMITMENTS):
+        p.commitments[k] = oracle.g1_mul(G, ints_to_limbs([i * 977 + 3], 4)[0]) if i != 4 else np.zeros(12, np.uint64)
+    for i, k in enumerate(Proof.EVALUATIONS):
+        p.evaluations[k] = fr_to_limbs((i + 1) * 0x123456789ABCDEF % R_MOD)
+    blob = p.to_bytes()
+    assert len(blob) == 11 * 48 + 10 * 32
+    q = Proof.from_bytes(blob)
+    assert all(np.array_equal(q.commitments[k], p.commitments[k]) for k in Proof.COMMITMENTS)
+    assert all(np.array_equal(q.evaluations[k], p.evaluations[k]) for k in Proof.EVALUATIONS)
+    assert q.to_bytes() == blob
+    import pytest
+    with pytest.raises(ValueError):
+        Proof.from_bytes(blob[:-1])
+    with pytest.raises(ValueError):
+        Proof.from_bytes(blob[:-32] + b"\xff" * 32)
