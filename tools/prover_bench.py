@@ -1,5 +1,6 @@
 """Wall time and per-kernel time of prove() on a synthetic chain circuit.
-usage: python tools/prover_bench.py LOG_N [REPS]"""
+usage: python tools/prover_bench.py LOG_N [REPS] [wide]
+"wide" uses synthetic.wide_circuit (generated with the GPU's help in seconds; for 2^22 and up)."""
 import os
 import sys
 import time
@@ -15,21 +16,30 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = 1 << log_n
 orc = CpuOracle()
 t0 = time.time()
-circuit, wit, pi = pa.synthetic.chain_circuit(n, 1)
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+ctx = pa.Context(0)
+if wide:
+    circuit, dw, _ = pa.synthetic.wide_circuit(n, ctx, 1)
+    pi = np.zeros((n, 4), np.uint64)
+else:
+    circuit, wit, pi = pa.synthetic.chain_circuit(n, 1)
 print(f"circuit 2^{log_n}: {time.time() - t0:.1f}s host", flush=True)
 k0, d = ints_to_limbs([0x1234567], 4)[0], ints_to_limbs([0x9E3779B9], 4)[0]
+t0 = time.time()
 srs = orc.g1_bases_arith(k0, d, n, threads=16)
-ctx = pa.Context(0)
+print(f"srs stand-in: {time.time() - t0:.1f}s host", flush=True)
 ck = pa.CommitKey(srs, ctx, precompute=True)
 t0 = time.time()
 pk = pa.preprocess(circuit, ctx)
 ctx.sync()
 print(f"preprocess: {time.time() - t0:.3f}s", flush=True)
-dw = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
+if not wide:
+    dw = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
+del circuit
 dpi = pa.DeviceVector.from_host(ctx, pi)
 proof = pa.prove(pk, ck, dw, dpi)
-pi_z = pa.field.fr_from_limbs(orc.fr_poly_evaluate(orc.fr_ntt(pi, log_n, 1, threads=16),
-                                                   pa.field.fr_to_limbs(proof.challenges["z"])))
+pi_z = 0 if wide else pa.field.fr_from_limbs(orc.fr_poly_evaluate(orc.fr_ntt(pi, log_n, 1, threads=16),
+                                                                  pa.field.fr_to_limbs(proof.challenges["z"])))
 print("identity:", pa.prover.check_identity(proof, n, pi_z), flush=True)
 best = 1e9
 for _ in range(reps):
