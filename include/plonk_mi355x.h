@@ -116,6 +116,8 @@ int pm_g1_bases_upload(pm_ctx* ctx, const uint64_t* xy, size_t n, pm_bases** out
  * ((ceil(256/c) - 1) x 96 n extra bytes; about 8 MSMs of time, once).  Every later MSM on these
  * bases then needs one bucket set and no doublings: ~15 % faster.  window_bits 0 = default (log2 n, at most 20). */
 int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t window_bits);
+/* The same from affine points already in device memory (n x 96 bytes, the layout above). */
+int pm_g1_bases_from_dev(pm_ctx* ctx, const void* d_xy, size_t n, pm_bases** out);
 void pm_g1_bases_free(pm_ctx* ctx, pm_bases* bases);
 size_t pm_g1_bases_len(const pm_bases* bases);
 
@@ -138,6 +140,13 @@ int pm_g1_msm_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n,
 int pm_g1_msm_batch_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars,
                         size_t scalar_stride, uint32_t batch, uint32_t scalar_form, uint64_t* out_xyz,
                         void* hip_stream);
+
+/* out[i] = scalars[i] * base for device-resident scalars; affine results (n x 96 bytes, (0, 0) =
+ * identity) in device memory.  SRS generation: with scalars = tau^i
+ * (pm_fr_powers_dev) this is the powers_of_g of dusk_plonk's PublicParameters::setup, which upstream
+ * computes on the CPU with a windowed single-base multiplication.  Blocks until done. */
+int pm_g1_fixed_base_mul_dev(pm_ctx* ctx, const uint64_t base_xy[12], const void* d_scalars, size_t n,
+                             uint32_t scalar_form, void* d_out_xy, void* hip_stream);
 
 /* out = sum of k projective points (the group-law "all-reduce" after an all-gather). Host. */
 int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]);

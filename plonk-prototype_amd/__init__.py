@@ -11,6 +11,6 @@ from ._lib import (BackendMissing, NTT_COSET, NTT_INVERSE, SCALAR_CANONICAL,  # 
 from .host import (CommitKey, Context, DeviceVector, Error, EvaluationDomain, Polynomial,  # noqa: F401
                    msm_variable_base,
                    g1_fold, g1_to_affine, domain_info, ntt_plan)
-from . import field, prover, synthetic, transcript  # noqa: F401,E402
+from . import field, prover, srs, synthetic, transcript  # noqa: F401,E402
 from .prover import Circuit, Proof, ProverKey, preprocess, prove  # noqa: F401,E402
 from .transcript import Transcript  # noqa: F401,E402

@@ -44,6 +44,9 @@ SIGNATURES = {
     "pm_fr_ntt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                 C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pm_g1_bases_upload": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pm_g1_bases_from_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pm_g1_fixed_base_mul_dev": (C.c_int, [C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                           C.c_void_p]),
     "pm_g1_bases_precompute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "pm_g1_bases_free": (None, [C.c_void_p, C.c_void_p]),
     "pm_g1_bases_len": (C.c_size_t, [C.c_void_p]),

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(128) precompute_double_kernel(const u32x4* src
   st_xyzz(scratch, i, p);
 }
 __global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scratch, size_t n, u32 per, u32x4* prefix,
-                                                                u32x4* dst) {
+                                                                u32x4* dst, u32 to_abi = 0) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const Fp one = fe_one<FpP>();
@@ -142,8 +142,13 @@ __global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scr
     inv = fe_mul<FpP>(inv, p.zzz);
     Fp t2 = fe_mul<FpP>(zi, p.zz);                            // ZZ / ZZZ
     Fp zzi = fe_sqr<FpP>(t2);                                 // ZZ^2 / ZZZ^2 = 1 / ZZ
-    fe_store<FpP>(o, fe_mul<FpP>(p.x, zzi));
-    fe_store<FpP>(o + 3, fe_mul<FpP>(p.y, zi));
+    Fp ax = fe_mul<FpP>(p.x, zzi), ay = fe_mul<FpP>(p.y, zi);
+    if (to_abi) {   // device form (x 2^392) -> ABI Montgomery (x 2^384) for results handed back to the caller
+      ax = fe_mul<FpP>(ax, fe_pow2<FpP, 384>());
+      ay = fe_mul<FpP>(ay, fe_pow2<FpP, 384>());
+    }
+    fe_store<FpP>(o, ax);
+    fe_store<FpP>(o + 3, ay);
   }
 }
 
@@ -654,6 +659,35 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   return PM_OK;
 }
 
+// ------------------------------------------------------------------ fixed-base multiplication
+// out[i] = scalars[i] * B from the table T[w][d-1] = d 2^(8 w) B (32 rows of 255 affine points, the
+// layout pm_g1_bases_precompute(window_bits = 8) builds from the row [B, 2B, .. 255B]): at most 32
+// mixed additions per scalar, no doublings.  SRS generation: powers_of_g[i] = tau^i G.
+__global__ void __launch_bounds__(128) fixed_base_kernel(const u32x4* scalars, size_t n, u32 scalar_form,
+                                                         const u32x4* table, u32x4* scratch) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = fe_load<FrP>(scalars + 2 * i);
+  Fr f;
+  if (scalar_form == PM_SCALAR_MONTGOMERY) {
+    f = fe_zero<FrP>();
+    f.l[0] = 32u;
+  } else {
+    f = fe_one<FrP>();
+  }
+  u32 w[8];
+  fe_canon_pack<FrP>(w, fe_mul<FrP>(s, f));
+  Xyzz acc = xyzz_identity();
+  for (u32 k = 0; k < 32; ++k) {
+    const u32 d = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+    if (d) {
+      const u32x4* p = table + 6 * ((size_t)k * 255 + d - 1);
+      acc = xyzz_madd(acc, fe_load<FpP>(p), fe_load<FpP>(p + 3));
+    }
+  }
+  st_xyzz(scratch, i, acc);
+}
+
 }  // namespace pm
 
 // ------------------------------------------------------------------ C ABI
@@ -742,7 +776,7 @@ extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t win
     const u32x4* src = (const u32x4*)table + 6 * n * (w - 1);
     u32x4* dst = (u32x4*)table + 6 * n * w;
     hipLaunchKernelGGL(precompute_double_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, src, n, c, scratch);
-    hipLaunchKernelGGL(precompute_affine_kernel, dim3(blocks), dim3(128), 0, st, (const u32x4*)scratch, n, per, prefix, dst);
+    hipLaunchKernelGGL(precompute_affine_kernel, dim3(blocks), dim3(128), 0, st, (const u32x4*)scratch, n, per, prefix, dst, 0u);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -822,4 +856,96 @@ extern "C" int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_
   }
   if (is_identity) *is_identity = ok ? 0 : 1;
   return PM_OK;
+}
+
+// Device-resident affine points (ABI layout) -> pm_bases, no host round trip (an SRS generated or
+// received on the GPU).
+extern "C" int pm_g1_bases_from_dev(pm_ctx* ctx, const void* d_xy, size_t n, pm_bases** out) {
+  if (!ctx || !out || (!d_xy && n)) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *out = nullptr;
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  pm_bases* b = new pm_bases();
+  b->n = n;
+  b->device = ctx->device;
+  if (n) {
+    hipError_t e = hipMalloc(&b->d_xy, n * 96);
+    if (e != hipSuccess) {
+      delete b;
+      return set_err(ctx, PM_ERR_OOM, "hipMalloc for bases failed");
+    }
+    hipLaunchKernelGGL(bases_convert_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const u32x4*)d_xy, (u32x4*)b->d_xy, 2 * n);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(b->d_xy);
+      delete b;
+      return set_err(ctx, PM_ERR_HIP, std::string("bases from device: ") + hipGetErrorString(e));
+    }
+  }
+  *out = b;
+  return PM_OK;
+}
+
+extern "C" int pm_g1_fixed_base_mul_dev(pm_ctx* ctx, const uint64_t base_xy[12], const void* d_scalars, size_t n,
+                                        uint32_t scalar_form, void* d_out_xy, void* hip_stream) {
+  if (!ctx || !base_xy) return PM_ERR_BAD_ARG;
+  if (scalar_form > PM_SCALAR_CANONICAL) return set_err(ctx, PM_ERR_BAD_ARG, "scalar_form");
+  if (n == 0) return PM_OK;
+  if (!d_scalars || !d_out_xy) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "n > 2^31");
+  // row 0 of the table on the host: d B for d = 1..255 (ABI Montgomery affine)
+  using host::HFp;
+  HFp bx, by;
+  memcpy(bx.l, base_xy, 48);
+  memcpy(by.l, base_xy + 6, 48);
+  std::vector<uint64_t> row(255 * 12, 0);
+  if (!(host::is_zero(bx) && host::is_zero(by))) {
+    XYZZ b1;
+    b1.x = bx;
+    b1.y = by;
+    b1.zz = host::one(host::FP());
+    b1.zzz = host::one(host::FP());
+    XYZZ cur = b1;
+    for (int d = 1; d <= 255; ++d) {
+      HFp x, y;
+      if (host::xyzz_to_affine(cur, x, y)) {
+        memcpy(&row[12 * (d - 1)], x.l, 48);
+        memcpy(&row[12 * (d - 1) + 6], y.l, 48);
+      }
+      cur = host::xyzz_add(cur, b1);
+    }
+  }
+  pm_bases* tb = nullptr;
+  int rc = pm_g1_bases_upload(ctx, row.data(), 255, &tb);
+  if (rc) return rc;
+  rc = pm_g1_bases_precompute(ctx, tb, 8);
+  if (rc) {
+    pm_g1_bases_free(ctx, tb);
+    return rc;
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipError_t e = hipSetDevice(ctx->device);
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    if (e == hipSuccess) rc = ensure_buffer(ctx, ctx->msm_ws, n * (256 + 64));
+    if (e == hipSuccess && !rc) {
+      u32x4* scratch = (u32x4*)ctx->msm_ws.ptr;
+      u32x4* prefix = scratch + 16 * n;
+      const size_t want = std::max<size_t>((n + 63) / 64, std::min<size_t>(n, (size_t)ctx->num_cus * 512));
+      const unsigned blocks = (unsigned)((want + 127) / 128);
+      const u32 per = (u32)((n + (size_t)blocks * 128 - 1) / ((size_t)blocks * 128));
+      ProfScope prof(ctx, st, "g1_fixed_base_mul");
+      hipLaunchKernelGGL(fixed_base_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, (const u32x4*)d_scalars, n,
+                         scalar_form, (const u32x4*)tb->d_table, scratch);
+      hipLaunchKernelGGL(precompute_affine_kernel, dim3(blocks), dim3(128), 0, st, (const u32x4*)scratch, n, per, prefix,
+                         (u32x4*)d_out_xy, 1u);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(st);   // the table is freed below
+    }
+    if (e != hipSuccess) rc = set_err(ctx, PM_ERR_HIP, std::string("fixed-base mul: ") + hipGetErrorString(e));
+  }
+  pm_g1_bases_free(ctx, tb);
+  return rc;
 }

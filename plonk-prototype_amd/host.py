@@ -369,6 +369,13 @@ def _one_mont() -> np.ndarray:
                     dtype=np.uint64)
 
 
+# G1 generator, affine Montgomery limbs (dusk_bls12_381::G1Affine::generator())
+G1_GENERATOR = np.array([0x5CB38790FD530C16, 0x7817FC679976FFF5, 0x154F95C7143BA1C1, 0xF0AE6ACDF3D0E747,
+                         0xEDCE6ECC21DBF440, 0x120177419E0BFB75, 0xBAAC93D50CE72271, 0x8C22631A7918FD8E,
+                         0xDD595F13570725CE, 0x51AC582950405194, 0x0E1C8C3FAD0059C0, 0x0BBC3EFC5008A26A],
+                        dtype=np.uint64)
+
+
 # --------------------------------------------------------------------------- MSM
 class Bases:
     """Device-resident affine bases (``pm_bases``)."""
@@ -381,6 +388,16 @@ class Bases:
         src = p if self.n else np.zeros((1, 12), np.uint64)
         ctx._check(ctx._lib.pm_g1_bases_upload(ctx._h, _p(src), self.n, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_device(cls, ctx: Context, d_xy: int, n: int) -> "Bases":
+        """Affine points already in device memory (n x 96 bytes, ABI layout)."""
+        self = object.__new__(cls)
+        self.ctx, self.n = ctx, n
+        h = C.c_void_p()
+        ctx._check(ctx._lib.pm_g1_bases_from_dev(ctx._h, C.c_void_p(d_xy), n, C.byref(h)))
+        self._h = h
+        return self
 
     def precompute(self, window_bits: int = 0):
         """Build the resident table of window multiples (``pm_g1_bases_precompute``)."""
@@ -474,6 +491,34 @@ class CommitKey:
         self._bases = Bases(self.ctx, powers_of_g)
         if precompute:      # a long-lived SRS: trade HBM for ~20 % faster commits
             self._bases.precompute()
+
+    @classmethod
+    def setup(cls, max_degree: int, tau, ctx: Context | None = None, precompute: bool = False,
+              generator=None, host_copy: bool = False) -> "CommitKey":
+        """``PublicParameters::setup(max_degree, rng).commit_key``: powers_of_g[i] = tau^i G for
+        i <= max_degree, generated on the GPU (powers of tau, then a fixed-base multiplication) and kept
+        there.  tau: Montgomery limbs [4] -- the toxic waste; for tests and benchmarks only, as upstream's
+        ``setup`` is.  generator: affine [12], default the G1 generator.  host_copy=True also downloads
+        the points into ``self.powers_of_g`` ([n, 12])."""
+        ctx = ctx or default_context()
+        n = max_degree + 1
+        g = G1_GENERATOR if generator is None else np.ascontiguousarray(generator, dtype=np.uint64).reshape(12)
+        powers = DeviceVector(ctx, n)
+        pts = DeviceVector(ctx, 3 * n)                            # n affine points of 96 bytes
+        try:
+            ctx.fr_powers(tau, _one_mont(), n, powers.ptr)
+            ctx._check(ctx._lib.pm_g1_fixed_base_mul_dev(ctx._h, _p(g), powers._p, n, _lib.SCALAR_MONTGOMERY, pts._p,
+                                                         None))
+            self = object.__new__(cls)
+            self.ctx = ctx
+            self._bases = Bases.from_device(ctx, pts.ptr, n)
+            self.powers_of_g = pts.to_host().reshape(n, 12) if host_copy else None
+        finally:
+            pts.free()
+            powers.free()
+        if precompute:
+            self._bases.precompute()
+        return self
 
     def max_degree(self) -> int:
         return self._bases.n - 1

@@ -208,3 +208,49 @@ def test_full_size_2_20(ctx, oracle):
     wl = np.tile(wl, (16, 1))
     dl = oracle.expected_dlog(wl, SCALAR_MONTGOMERY, K0, DD)
     assert np.array_equal(ck.commit(wl), oracle.g1_mul(oracle.g1_generator(), dl))
+
+
+@pytest.mark.parametrize("n", [1, 2, 300, 5000])
+def test_srs_setup_on_the_gpu(ctx, oracle, n):
+    """CommitKey.setup: powers_of_g[i] = tau^i G from the fixed-base kernel, against per-point
+    double-and-add in the oracle; then a commitment under the generated key."""
+    import plonk_prototype_amd as pa
+    from oracle import bigint_oracle as B
+    from oracle.cpu_oracle import ints_to_limbs, limbs_to_ints
+    tau = 0x6B8B4567327B23C6643C98696633487374B0DC5119495CFF2AE8944A625558EC % B.R_MOD
+    tau_m = oracle.fr_to_mont(ints_to_limbs([tau], 4))[0]
+    ck = pa.CommitKey.setup(n - 1, tau_m, ctx, host_copy=True)
+    G = oracle.g1_generator()
+    step = max(1, n // 40)
+    for i in list(range(0, n, step)) + [n - 1]:
+        assert np.array_equal(ck.powers_of_g[i], oracle.g1_mul(G, ints_to_limbs([pow(tau, i, B.R_MOD)], 4)[0])), i
+    assert all(oracle.g1_is_on_curve(ck.powers_of_g[i]) for i in range(0, n, step))
+    coeffs = oracle.fr_sample(n, n)
+    cv = limbs_to_ints(oracle.fr_from_mont(coeffs))
+    expect = oracle.g1_mul(G, ints_to_limbs([B.horner(cv, tau)], 4)[0])
+    assert np.array_equal(ck.commit(coeffs), expect)                 # commit(p) = p(tau) G
+
+
+def test_fixed_base_edge_scalars(ctx, oracle):
+    """Scalars 0, 1, r - 1, single-byte digits, and the identity as base."""
+    import ctypes as C
+    import plonk_prototype_amd as pa
+    from oracle import bigint_oracle as B
+    from oracle.cpu_oracle import ints_to_limbs
+    ks = [0, 1, B.R_MOD - 1, 255, 256, 0xFF00FF00FF, 1 << 200, (1 << 248) + 5]
+    sc = pa.DeviceVector.from_host(ctx, oracle.fr_to_mont(ints_to_limbs(ks, 4)))
+    out = pa.DeviceVector(ctx, 3 * len(ks))
+    P = oracle.g1_mul(oracle.g1_generator(), ints_to_limbs([0xABCDEF], 4)[0])
+    u64p = C.POINTER(C.c_uint64)
+    ctx._check(ctx._lib.pm_g1_fixed_base_mul_dev(ctx._h, P.ctypes.data_as(u64p), sc._p, len(ks), 0, out._p, None))
+    got = out.to_host().reshape(-1, 12)
+    for k, g in zip(ks, got):
+        assert np.array_equal(g, oracle.g1_mul(P, ints_to_limbs([k], 4)[0])), hex(k)
+    assert not got[0].any()
+    # canonical-form scalars give the same points
+    sc2 = pa.DeviceVector.from_host(ctx, ints_to_limbs(ks, 4))
+    ctx._check(ctx._lib.pm_g1_fixed_base_mul_dev(ctx._h, P.ctypes.data_as(u64p), sc2._p, len(ks), 1, out._p, None))
+    assert np.array_equal(out.to_host().reshape(-1, 12), got)
+    ident = np.zeros(12, np.uint64)
+    ctx._check(ctx._lib.pm_g1_fixed_base_mul_dev(ctx._h, ident.ctypes.data_as(u64p), sc._p, len(ks), 0, out._p, None))
+    assert not out.to_host().any()

@@ -107,3 +107,20 @@ def test_proof_serialisation_roundtrip(oracle):
         Proof.from_bytes(blob[:-1])
     with pytest.raises(ValueError):
         Proof.from_bytes(blob[:-32] + b"\xff" * 32)
+
+
+def test_commit_key_raw_bytes_roundtrip(oracle):
+    from oracle.cpu_oracle import ints_to_limbs
+    from plonk_prototype_amd import srs
+    pts = oracle.g1_bases_arith(ints_to_limbs([5], 4)[0], ints_to_limbs([9], 4)[0], 7, 1)
+    pts[3] = 0                                                   # an identity entry
+    blob = srs.commit_key_to_raw_bytes(pts)
+    assert len(blob) == 8 + 7 * 97 and blob[:8] == (7).to_bytes(8, "little")
+    assert blob[8 + 3 * 97 + 96] == 1 and blob[8 + 96] == 0     # infinity flags
+    assert blob[8:8 + 8] == int(pts[0, 0]).to_bytes(8, "little")  # raw Montgomery limbs, little-endian
+    assert np.array_equal(srs.commit_key_from_raw_bytes(blob), pts)
+    assert len(srs.commit_key_to_raw_bytes(np.zeros((0, 12), np.uint64))) == 8
+    import pytest
+    for bad in (blob[:-1], blob[:5], blob + b"\0"):
+        with pytest.raises(ValueError):
+            srs.commit_key_from_raw_bytes(bad)
