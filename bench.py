@@ -264,8 +264,15 @@ def main():
         gk = args.prover_log_n
         gn = 1 << gk
         circuit, wit, pub = pa.synthetic.chain_circuit(gn, 1)
+        tau = 0x1F2E3D4C5B6A79788796A5B4C3D2E1F00112233445566778899AABBCCDDEEFF % R_MOD
+        srs_ms = None
         if world == 1:
-            ck = pa.CommitKey(pts, ctx, precompute=True)            # the same SRS stand-in as the MSM leg
+            # a real powers-of-tau key, generated on the GPU (PublicParameters::setup), so that the opening
+            # equations can be checked at full size below
+            t0 = time.perf_counter()
+            ck = pa.CommitKey.setup(gn - 1, pa.field.fr_to_limbs(tau), ctx)
+            srs_ms = (time.perf_counter() - t0) * 1e3
+            ck._bases.precompute()
         else:
             ck = ShardedCommitKey(pts, shard_range(gn, rank, world)[0], gn, ctx, device=coll_dev, precompute=True)
         t0 = time.perf_counter()
@@ -278,9 +285,25 @@ def main():
         pub_z = pa.field.fr_from_limbs(oracle.fr_poly_evaluate(oracle.fr_ntt(pub, gk, INVERSE, cores),
                                                                pa.field.fr_to_limbs(proof.challenges["z"])))
         ident_ok = bool(pa.prover.check_identity(proof, gn, pub_z))
-        k0l, ddl = ints_to_limbs([k0], 4)[0], ints_to_limbs([dd], 4)[0]
-        dl = oracle.expected_dlog(oracle.fr_ntt(wit[0], gk, INVERSE, cores), 0, k0l, ddl)
-        comm_ok = bool(np.array_equal(proof.commitments["a"], oracle.g1_mul(oracle.g1_generator(), dl)))
+        fl, fi = pa.field.fr_to_limbs, pa.field.fr_from_limbs
+        G1 = oracle.g1_generator()
+        kzg_ok = None
+        if world == 1:
+            # commit(p) = [p(tau)] G and the opening equation W(tau) (tau - z) = F(tau) - F(z), with the
+            # polynomials still in the prover's workspace and evaluated on the device
+            ws = pkey._ws
+            a_tau = fi(ctx.fr_evaluate(ws["coeffs"].ptr, gn, fl(tau)))
+            comm_ok = bool(np.array_equal(proof.commitments["a"], oracle.g1_mul(G1, ints_to_limbs([a_tau], 4)[0])))
+            zc = proof.challenges["z"]
+            w_tau = fi(ctx.fr_evaluate(ws["wit"].ptr, gn - 1, fl(tau)))
+            f_tau, f_z = (fi(ctx.fr_evaluate(ws["agg"].ptr, gn, fl(x_))) for x_ in (tau, zc))
+            kzg_ok = bool(w_tau * (tau - zc) % R_MOD == (f_tau - f_z) % R_MOD and
+                          np.array_equal(proof.commitments["w_z"], oracle.g1_mul(G1, ints_to_limbs([w_tau], 4)[0])))
+            assert kzg_ok, "opening witness fails the KZG equation"
+        else:
+            k0l, ddl = ints_to_limbs([k0], 4)[0], ints_to_limbs([dd], 4)[0]
+            dl = oracle.expected_dlog(oracle.fr_ntt(wit[0], gk, INVERSE, cores), 0, k0l, ddl)
+            comm_ok = bool(np.array_equal(proof.commitments["a"], oracle.g1_mul(G1, dl)))
         assert ident_ok and comm_ok, "prover output fails the verifier identity / commitment check"
         reps = 5
         barrier()
@@ -310,6 +333,7 @@ def main():
                   "kernel_ms": {k_: round(v_, 3) for k_, v_ in grp.items()},
                   "kernel_ms_total": round(sum(grp.values()), 2), "preprocess_ms": round(t_pre * 1e3, 1),
                   "verifier_identity_holds": ident_ok, "commitment_matches_dlog": comm_ok,
+                  "kzg_opening_equation_holds": kzg_ok, "srs_setup_ms": round(srs_ms, 1) if srs_ms else None,
                   "inputs": "witness and public inputs resident in HBM; proving key and SRS table resident"}
         for v_ in (d_wit, d_pub):
             v_.free()
