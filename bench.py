@@ -27,8 +27,8 @@ HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--msm-log-n", type=int, default=20)
     ap.add_argument("--msm-steps", type=int, default=5)

@@ -144,7 +144,16 @@ extern "C" int pm_profile_enable(pm_ctx* ctx, int on) {
   (void)hipSetDevice(ctx->device);
   prof_collect(ctx);
   ctx->profile = on != 0;
-  if (on) ctx->prof_stats.clear();
+  if (on) {
+    ctx->prof_stats.clear();
+    // create the event pairs up front: hipEventCreate costs a few microseconds and must not sit
+    // between two kernels of the region being timed
+    while (ctx->prof_pool.size() < 4096) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      ctx->prof_pool.push_back(e);
+    }
+  }
   return PM_OK;
 }
 
