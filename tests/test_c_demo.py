@@ -1,0 +1,38 @@
+"""examples/abi_demo.c: the C ABI used from plain C (no Python, no torch in the process).
+CPU: it compiles against include/plonk_mi355x.h, links against the built library and fails loudly
+without a device.  GPU: it runs its NTT / MSM checks."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+LIBDIR = os.path.join(ROOT, "plonk-prototype_amd", "lib")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "abi_demo")
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "abi_demo.c"), "-I", os.path.join(ROOT, "include"),
+           "-L", LIBDIR, "-lplonk_mi355x", f"-Wl,-rpath,{LIBDIR}", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_c_demo_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the gpu-marked test runs the demo")
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "pm_init" in r.stderr and "-5" in r.stderr           # PM_ERR_NO_DEVICE, no silent CPU path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [3, 12, 18])
+def test_c_demo_runs_on_the_gpu(tmp_path, log_n):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, str(log_n)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "abi_demo OK" in r.stdout
