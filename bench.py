@@ -7,8 +7,13 @@ a forward and an inverse 2^20-point NTT (BASELINE.json configs[1]).  `value` is 
 butterflies/s over all ranks (weak scaling: every rank transforms its own polynomials, no
 collective on the data path).  The same JSON line carries the MSM leg (configs[2]: 2^20-point
 G1 MSM; with N > 1 the points are sharded over the ranks and the 144-byte partials are
-all-gathered over RCCL and folded), the roofline of the dominant kernel from live hipEvent
+all-gathered over RCCL and folded), the full-prove leg (configs[3]: a 2^20-gate synthetic circuit
+through plonk-prototype_amd/prover.py), the roofline of the dominant kernel from live hipEvent
 timings, and the CPU baseline (the oracle's C restatement, timed on this box's host cores).
+
+Role of oracle/ here: it is the CPU baseline, it synthesises seeded inputs with known answers
+(scalars, an SRS stand-in of known discrete logs) and it checks every leg's result after the timed
+region (asserts below).  Nothing that is timed on the GPU calls it.
 """
 import argparse
 import json
