@@ -112,3 +112,76 @@ def test_field_limb_patterns(ctx, oracle):
             got2 = ctx.field_op(base + op, a, b)               # raw limbs as Montgomery residues
             exp2 = tm(ints_to_limbs([fn(x, y) for x, y in zip(limbs_to_ints(fm(a)), limbs_to_ints(fm(b)))], nl))
             assert np.array_equal(got2, exp2), (nl, op, "raw")
+
+
+def test_prover_round_kernels_random_shapes(ctx, oracle):
+    """powers / lincomb / permutation terms on random lengths, with edge values salted in."""
+    import ctypes as C
+    import random
+    import plonk_prototype_amd as pa
+    from oracle import plonk_rounds_oracle as PO
+    from plonk_prototype_amd import _lib
+    R = B.R_MOD
+    rng = random.Random(424242)
+    edge = [0, 1, R - 1, R - 2, (1 << 255) % R, R // 2]
+
+    def rand_vec(n):
+        return [rng.choice(edge) if rng.random() < 0.1 else rng.randrange(R) for _ in range(n)]
+
+    def dev(vals):
+        return pa.DeviceVector.from_host(ctx, oracle.fr_to_mont(ints_to_limbs(vals, 4)))
+
+    def ints(dv):
+        return limbs_to_ints(oracle.fr_from_mont(dv.to_host()))
+
+    def mont(v):
+        return oracle.fr_to_mont(ints_to_limbs([v % R], 4))[0]
+
+    for case in range(25):
+        n = rng.randrange(1, 2500)
+        base, scale = rng.choice(edge + [rng.randrange(R)]), rng.choice(edge + [rng.randrange(R)])
+        out = pa.DeviceVector(ctx, n)
+        ctx.fr_powers(mont(base), mont(scale), n, out.ptr)
+        assert ints(out) == PO.powers(base, scale, n), ("powers", case, n)
+        k = rng.randrange(1, 17)
+        vecs, coeffs = [rand_vec(n) for _ in range(k)], rand_vec(k)
+        dv = [dev(v) for v in vecs]
+        ctx.fr_lincomb([d.ptr for d in dv], oracle.fr_to_mont(ints_to_limbs(coeffs, 4)), n, out.ptr)
+        assert ints(out) == PO.lincomb(coeffs, vecs), ("lincomb", case, n, k)
+        wires, sigmas, roots = [rand_vec(n) for _ in range(4)], [rand_vec(n) for _ in range(4)], rand_vec(n)
+        beta, gamma = rng.choice(edge + [rng.randrange(R)]), rng.randrange(R)
+        dw, ds, dr = [dev(v) for v in wires], [dev(v) for v in sigmas], dev(roots)
+        a = _lib.PermArgs()
+        for j in range(4):
+            a.wires[j], a.sigmas[j] = dw[j].ptr, ds[j].ptr
+        a.roots = dr.ptr
+        u = lambda v: (C.c_uint64 * 4)(*[int(x) for x in mont(v)])   # noqa: E731
+        a.beta, a.gamma = u(beta), u(gamma)
+        for j, kk in enumerate((7, 13, 17)):
+            a.k[j] = u(kk)
+        num, den = pa.DeviceVector(ctx, n), pa.DeviceVector(ctx, n)
+        ctx.plonk_perm_terms(a, n, num.ptr, den.ptr)
+        en, ed = PO.perm_terms(wires, sigmas, roots, beta, gamma)
+        assert ints(num) == en and ints(den) == ed, ("perm", case, n)
+
+
+def test_prove_many_seeds(ctx, oracle):
+    """Several circuits and sizes: every proof must satisfy the verifier identity, and the serialised
+    proof must round-trip."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    srs = oracle.g1_bases_arith(ints_to_limbs([11], 4)[0], ints_to_limbs([0x10001], 4)[0], 2048, 8)
+    for seed, n in ((1, 8), (2, 32), (3, 128), (4, 512), (5, 2048)):
+        circuit, wit, pub = pa.synthetic.chain_circuit(n, seed)
+        pk = PR.preprocess(circuit, ctx)
+        ck = pa.CommitKey(srs[:n], ctx, precompute=(seed % 2 == 0))
+        proof = PR.prove(pk, ck, wit, pub)
+        pub_c = oracle.fr_ntt(pub, n.bit_length() - 1, INVERSE)
+        pub_z = limbs_to_ints(oracle.fr_from_mont(
+            oracle.fr_poly_evaluate(pub_c, oracle.fr_to_mont(ints_to_limbs([proof.challenges["z"]], 4))[0]).reshape(1, 4)))[0]
+        assert PR.check_identity(proof, n, pub_z), (seed, n)
+        blob = proof.to_bytes()
+        assert PR.Proof.from_bytes(blob).to_bytes() == blob
+        # a second proof from the same key reuses the workspace and must be identical
+        again = PR.prove(pk, ck, wit, pub)
+        assert again.to_bytes() == blob
