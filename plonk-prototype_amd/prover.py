@@ -303,12 +303,44 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
     for name, c in zip(("w_z", "w_zw"), _commit_batch(ck, wit.ptr, n - 1, 2, n)):
         proof.commitments[name] = c
         ts.append_commitment(name.encode(), c)
-    proof.challenges = {"beta": beta, "gamma": gamma, "alpha": alpha, "z": zc, "v": v}
+    u = ts.challenge_scalar(b"u")                                  # separates the two opening checks of the verifier
+    proof.challenges = {"beta": beta, "gamma": gamma, "alpha": alpha, "z": zc, "v": v, "u": u}
     if own_witness:
         wire_evals.free()
     if own_pi:
         pi_ev.free()
     return proof
+
+
+def derive_challenges(proof: Proof, n: int, transcript: Transcript | None = None) -> dict:
+    """The verifier's side of Fiat-Shamir: replay the transcript over the proof's commitments and
+    evaluations (same labels and order as prove()) and return the challenges."""
+    ts = transcript or Transcript(b"plonk")
+    ts.circuit_domain_sep(n)
+    for name in ("a", "b", "c", "d"):
+        ts.append_commitment(b"w_" + name.encode(), proof.commitments[name])
+    ch = {"beta": ts.challenge_scalar(b"beta"), "gamma": ts.challenge_scalar(b"gamma")}
+    ts.append_commitment(b"z", proof.commitments["z"])
+    ch["alpha"] = ts.challenge_scalar(b"alpha")
+    for i in range(4):
+        ts.append_commitment(f"t_{i + 1}".encode(), proof.commitments[f"t_{i + 1}"])
+    ch["z"] = ts.challenge_scalar(b"z")
+    for name in Proof.EVALUATIONS:
+        ts.append_scalar(name.encode() + b"_eval", proof.evaluations[name])
+    ch["v"] = ts.challenge_scalar(b"v")
+    for name in ("w_z", "w_zw"):
+        ts.append_commitment(name.encode(), proof.commitments[name])
+    ch["u"] = ts.challenge_scalar(b"u")
+    return ch
+
+
+def verifier_key(pk: ProverKey, ck) -> dict:
+    """Commitments to the selector and sigma polynomials (``dusk_plonk::proof_system::VerifierKey``'s
+    G1 part), computed from the prover key's device-resident coefficients."""
+    out = dict(zip(SELECTORS, ck.commit_batch_dev(pk.sel_coeffs.ptr, pk.n, len(SELECTORS), pk.n)))
+    for j, c in enumerate(ck.commit_batch_dev(pk.sigma_coeffs.ptr, pk.n, 4, pk.n)):
+        out[f"sigma_{j + 1}"] = c
+    return out
 
 
 def check_identity(proof: Proof, n: int, pi_eval: int = 0) -> bool:

@@ -289,3 +289,44 @@ def test_wide_circuit_is_satisfied_and_proves(ctx, oracle):
     proof = PR.prove(PR.preprocess(circuit, ctx), pa.CommitKey(srs, ctx), d_wit, None)
     assert PR.check_identity(proof, n, 0)
     assert PR.Proof.from_bytes(proof.to_bytes()).to_bytes() == proof.to_bytes()
+
+
+def _pt(oracle, xy):
+    """affine Montgomery limbs [12] -> (x, y) ints or None."""
+    if not np.asarray(xy).any():
+        return None
+    v = limbs_to_ints(oracle.fp_from_mont(np.ascontiguousarray(xy).reshape(2, 6)))
+    return (v[0], v[1])
+
+
+@pytest.mark.parametrize("n", [16, 128])
+def test_gpu_proof_passes_the_pairing_verifier(ctx, oracle, n):
+    """End to end without the prover-side oracle: SRS generated on the GPU, proof made on the GPU,
+    challenges re-derived from the proof bytes by replaying the transcript, then the verifier's
+    scalar identity and the KZG pairing equation (oracle/plonk_verifier_oracle.py, plain-Python
+    pairing).  Tampered proofs must fail."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from oracle import pairing_oracle as PG
+    from oracle import plonk_verifier_oracle as PV
+    tau = TAU
+    circuit, wit, pub = pa.synthetic.chain_circuit(n, 77 + n)
+    ck = pa.CommitKey.setup(n - 1, _mont(oracle, tau), ctx, precompute=(n > 16))
+    pk = PR.preprocess(circuit, ctx)
+    proof = PR.Proof.from_bytes(PR.prove(pk, ck, wit, pub).to_bytes())        # what a verifier receives
+    ch = PR.derive_challenges(proof, n)
+    vk = {k: _pt(oracle, v) for k, v in PR.verifier_key(pk, ck).items()}
+    comms = {k: _pt(oracle, v) for k, v in proof.commitments.items()}
+    ev = {k: _ints(oracle, v)[0] for k, v in proof.evaluations.items()}
+    pub_z = B.horner(B.ifft(_ints(oracle, pub), n.bit_length() - 1), ch["z"])
+    tau_g2 = PG.g2_mul(tau, PG.G2_GEN)
+    assert PV.verify(n, vk, comms, ev, ch, pub_z, tau_g2) == (True, True)
+    # the prover derived the same challenges
+    assert ch == PR.prove(pk, ck, wit, pub).challenges
+    if n == 16:
+        bad = dict(ev, c=(ev["c"] + 1) % R)
+        assert PV.verify(n, vk, comms, bad, ch, pub_z, tau_g2) == (False, False)
+        swapped = dict(comms, t_1=comms["t_2"], t_2=comms["t_1"])
+        assert PV.verify(n, vk, swapped, ev, ch, pub_z, tau_g2)[1] is False
+        # a proof for a different witness does not verify against tampered public inputs
+        assert PV.verify(n, vk, comms, ev, ch, (pub_z + 1) % R, tau_g2)[0] is False
