@@ -144,6 +144,33 @@ def main():
                 "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()}, "valu": valu,
                 "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
 
+    # ------------------------------------------------------------------ NTT extras (rank 0): SURVEY 8d
+    ntt_extra = None
+    if rank == 0:
+        # (i) the host-pointer ABI call (what a patched dusk-plonk `fft` makes): H2D + NTT + D2H
+        ctx.fr_ntt(host_in, k, 0)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            host_out = ctx.fr_ntt(host_in, k, 0)
+        e2e = (time.perf_counter() - t0) / reps
+        assert np.array_equal(host_out, d_b.cpu().numpy().view(np.uint64)), "host-pointer NTT != device-resident NTT"
+        # (ii) the prover's shape: coset NTT of a 2^k-coefficient polynomial on the 4x domain
+        d4 = torch.empty((4 * n, 4), dtype=torch.int64, device=dev)
+        for _ in range(3):
+            ctx.fr_ntt_dev(d_a.data_ptr(), n, d4.data_ptr(), k + 2, pa.NTT_COSET, stream=stream)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.fr_ntt_dev(d_a.data_ptr(), n, d4.data_ptr(), k + 2, pa.NTT_COSET, stream=stream)
+        barrier()
+        c4 = (time.perf_counter() - t0) / 20
+        ntt_extra = {"pcie_inclusive": {"ms_per_transform": round(e2e * 1e3, 3), "butterflies_per_s": (n // 2) * k / e2e,
+                                        "note": "pm_fr_ntt with pageable host buffers: H2D + transform + D2H; never `value`"},
+                     "coset_4n": {"log_n": k + 2, "in_len": n, "us_per_transform": round(c4 * 1e6, 1),
+                                  "butterflies_per_s": (2 * n) * (k + 2) / c4}}
+        del d4
+
     # ------------------------------------------------------------------ MSM legs
     tpath_exists = os.path.exists(tpath)
     k0, dd = 0x1234567, 0xabcdef123456789abcdef
@@ -193,6 +220,28 @@ def main():
                                         if tpath_exists and world == 1 else None)}}
         assert ok, "MSM result differs from the discrete-log identity"
         if table and world == 1 and mk <= 20:
+            # "witness-like" scalars: 90 % below 2^16, 5 % zero, 1 % one -- bucket skew and shortcuts
+            rs = np.random.default_rng(0x5343414C)
+            wl = full_sc.copy()
+            u_ = rs.random(mn)
+            small = oracle.fr_to_mont(np.concatenate([rs.integers(0, 1 << 16, size=(mn, 1), dtype=np.uint64),
+                                                      np.zeros((mn, 3), np.uint64)], axis=1))
+            wl[u_ < 0.90] = small[u_ < 0.90]
+            wl[(u_ >= 0.90) & (u_ < 0.95)] = 0
+            wl[(u_ >= 0.95) & (u_ < 0.96)] = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+            d_wl = torch.from_numpy(np.ascontiguousarray(wl).view(np.int64)).to(dev)
+            rw = bases.msm_dev(d_wl.data_ptr(), mn, stream=stream)
+            dlw = oracle.expected_dlog(wl, 0, ints_to_limbs([k0], 4)[0], ints_to_limbs([dd], 4)[0])
+            okw = bool(np.array_equal(pa.g1_to_affine(rw)[0], oracle.g1_mul(oracle.g1_generator(), dlw)))
+            assert okw, "witness-like MSM differs from the discrete-log identity"
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                bases.msm_dev(d_wl.data_ptr(), mn, stream=stream)
+            barrier()
+            wdt = (time.perf_counter() - t0) / steps
+            out["witness_like"] = {"ms_per_msm": wdt * 1e3, "value": mn / wdt, "bit_exact_vs_oracle": okw,
+                                   "note": "90 % of scalars < 2^16, 5 % zero, 1 % one, rest uniform"}
             # a prover round: 4 wire polynomials committed in one pass over the same SRS
             kb = 4
             sc4 = np.concatenate([sc] + [oracle.fr_sample(0x5343414D + j, mn) for j in range(1, kb)])
@@ -387,7 +436,7 @@ def main():
                "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "
                                       f"natural order in/out, bit-exact vs oracle", "log_n": k, "passes": passes,
                           "parallelism": f"{world} independent polynomial(s), one per GPU"},
-               "roofline": roofline, "cpu_baseline": cpu, "msm": msm, "msm_large": msm_large, "next_rows": poly,
+               "roofline": roofline, "cpu_baseline": cpu, "ntt_extra": ntt_extra, "msm": msm, "msm_large": msm_large, "next_rows": poly,
                "prover": prover}
         print(json.dumps(out))
     ctx.close()
