@@ -2,7 +2,6 @@
 and the verifier oracle accepts the prover oracle's proofs and rejects tampered ones."""
 import random
 
-import pytest
 
 from oracle import bigint_oracle as B
 from oracle import pairing_oracle as PG
