@@ -771,3 +771,149 @@ void orc_fr_prefix_product(const u64 *a, size_t n, u64 *out) {
     fr_mul(acc, acc, a + 4 * i);
   }
 }
+
+/* ------------------------------------------------------------------ PLONK prover rounds (N1)
+ * The pointwise steps of dusk-plonk 0.8.2's prover (ref:Cargo.toml:19; permutation::
+ * compute_permutation_poly, quotient_poly::compute, linearisation_poly::compute) for the arithmetic
+ * gate and the 4-wire permutation, written from the protocol equations.  Used by
+ * oracle/cpu_prover.py: the CPU baseline of a full proof and a fast second oracle for the GPU
+ * prover at sizes the big-int oracle cannot reach.  PARITY UNPINNED (no upstream vectors). */
+static void fr_from_small(u64 *r, u64 v) { fr_from_u64(r, v); }
+
+/* out[i] = scale * base^i */
+void orc_fr_powers(const u64 *base, const u64 *scale, size_t n, u64 *out) {
+  orc_init();
+  u64 cur[4];
+  memcpy(cur, scale, 32);
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(out + 4 * i, cur, 32);
+    fr_mul(cur, cur, base);
+  }
+}
+/* out = sum_j coeffs[j] * vecs[j] */
+void orc_fr_lincomb(unsigned k, const u64 *const *vecs, const u64 *coeffs, size_t n, u64 *out, int threads) {
+  orc_init();
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    u64 acc[4] = {0, 0, 0, 0}, t[4];
+    for (unsigned j = 0; j < k; ++j) {
+      fr_mul(t, vecs[j] + 4 * i, coeffs + 4 * j);
+      fr_add(acc, acc, t);
+    }
+    memcpy(out + 4 * i, acc, 32);
+  }
+}
+/* util::batch_inversion with Montgomery's trick (zeros stay zero); one inversion per thread block */
+void orc_fr_batch_inverse_trick(u64 *v, size_t n, int threads) {
+  orc_init();
+  const int T = threads > 0 ? threads : 1;
+#pragma omp parallel for num_threads(T) schedule(static)
+  for (int b = 0; b < T; ++b) {
+    const size_t lo = n * (size_t)b / T, hi = n * (size_t)(b + 1) / T;
+    if (hi <= lo) continue;
+    u64 *pre = (u64 *)malloc(32 * (hi - lo));
+    u64 acc[4];
+    memcpy(acc, FR.one, 32);
+    for (size_t i = lo; i < hi; ++i) {
+      memcpy(pre + 4 * (i - lo), acc, 32);
+      if (!is_zero_n(v + 4 * i, 4)) fr_mul(acc, acc, v + 4 * i);
+    }
+    f_inv(acc, acc, &FR);
+    for (size_t i = hi; i-- > lo;) {
+      if (is_zero_n(v + 4 * i, 4)) continue;
+      u64 t[4];
+      fr_mul(t, acc, pre + 4 * (i - lo));
+      fr_mul(acc, acc, v + 4 * i);
+      memcpy(v + 4 * i, t, 32);
+    }
+    free(pre);
+  }
+}
+/* num[i] = prod_j (w_j[i] + beta k_j roots[i] + gamma), den[i] = prod_j (w_j[i] + beta sigma_j[i] + gamma);
+ * k = {1, 7, 13, 17} */
+void orc_plonk_perm_terms(const u64 *const *w, const u64 *const *sig, const u64 *roots, const u64 *beta,
+                          const u64 *gamma, size_t n, u64 *num, u64 *den, int threads) {
+  orc_init();
+  u64 bk[4][4];
+  const u64 ks[4] = {1, 7, 13, 17};
+  for (int j = 0; j < 4; ++j) {
+    u64 kj[4];
+    fr_from_small(kj, ks[j]);
+    fr_mul(bk[j], beta, kj);
+  }
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    u64 a[4], b[4], t[4];
+    memcpy(a, FR.one, 32);
+    memcpy(b, FR.one, 32);
+    for (int j = 0; j < 4; ++j) {
+      fr_mul(t, bk[j], roots + 4 * i);
+      fr_add(t, t, w[j] + 4 * i);
+      fr_add(t, t, gamma);
+      fr_mul(a, a, t);
+      fr_mul(t, beta, sig[j] + 4 * i);
+      fr_add(t, t, w[j] + 4 * i);
+      fr_add(t, t, gamma);
+      fr_mul(b, b, t);
+    }
+    memcpy(num + 4 * i, a, 32);
+    memcpy(den + 4 * i, b, 32);
+  }
+}
+/* Quotient on the 4n coset, x[i] = 7 w_4n^i.  ptrs: w0..w3, z, q_m, q_l, q_r, q_o, q_4, q_c, pi, s0..s3, l1, x
+ * (18 arrays of 4n).  t[i] = (gate + alpha (z prod id - z(wX) prod copy) + alpha^2 (z - 1) l1) / (x^n - 1) */
+void orc_plonk_quotient(const u64 *const *p, size_t n, const u64 *alpha, const u64 *beta, const u64 *gamma, u64 *out,
+                        int threads) {
+  orc_init();
+  const size_t n4 = 4 * n;
+  const u64 *w[4] = {p[0], p[1], p[2], p[3]}, *z = p[4], *qm = p[5], *ql = p[6], *qr = p[7], *qo = p[8], *q4 = p[9],
+            *qc = p[10], *pi = p[11], *s[4] = {p[12], p[13], p[14], p[15]}, *l1 = p[16], *x = p[17];
+  u64 bk[4][4], alpha2[4], zh_inv[4][4];
+  const u64 ks[4] = {1, 7, 13, 17};
+  for (int j = 0; j < 4; ++j) {
+    u64 kj[4];
+    fr_from_small(kj, ks[j]);
+    fr_mul(bk[j], beta, kj);
+  }
+  fr_mul(alpha2, alpha, alpha);
+  for (int j = 0; j < 4 && (size_t)j < n4; ++j) { /* x^n - 1 only depends on i mod 4 */
+    u64 e[1] = {(u64)n}, t[4];
+    f_pow(t, x + 4 * j, e, 1, &FR);
+    fr_sub(t, t, FR.one);
+    f_inv(zh_inv[j], t, &FR);
+  }
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (size_t i = 0; i < n4; ++i) {
+    const size_t nx = (i + 4) % n4;
+    const u64 *a = w[0] + 4 * i, *b = w[1] + 4 * i, *c = w[2] + 4 * i, *d = w[3] + 4 * i;
+    u64 g[4], t[4], id[4], cp[4];
+    fr_mul(t, a, b);
+    fr_mul(g, t, qm + 4 * i);
+    fr_mul(t, ql + 4 * i, a); fr_add(g, g, t);
+    fr_mul(t, qr + 4 * i, b); fr_add(g, g, t);
+    fr_mul(t, qo + 4 * i, c); fr_add(g, g, t);
+    fr_mul(t, q4 + 4 * i, d); fr_add(g, g, t);
+    fr_add(g, g, qc + 4 * i);
+    fr_add(g, g, pi + 4 * i);
+    memcpy(id, z + 4 * i, 32);
+    memcpy(cp, z + 4 * nx, 32);
+    for (int j = 0; j < 4; ++j) {
+      fr_mul(t, bk[j], x + 4 * i);
+      fr_add(t, t, w[j] + 4 * i);
+      fr_add(t, t, gamma);
+      fr_mul(id, id, t);
+      fr_mul(t, beta, s[j] + 4 * i);
+      fr_add(t, t, w[j] + 4 * i);
+      fr_add(t, t, gamma);
+      fr_mul(cp, cp, t);
+    }
+    fr_sub(id, id, cp);
+    fr_mul(id, id, alpha);
+    fr_add(g, g, id);
+    fr_sub(t, z + 4 * i, FR.one);
+    fr_mul(t, t, l1 + 4 * i);
+    fr_mul(t, t, alpha2);
+    fr_add(g, g, t);
+    fr_mul(out + 4 * i, g, zh_inv[i & 3]);
+  }
+}

@@ -74,6 +74,12 @@ class CpuOracle:
             "orc_fr_poly_evaluate": [_u64p, C.c_size_t, _u64p, _u64p],
             "orc_fr_poly_ruffini": [_u64p, C.c_size_t, _u64p, _u64p],
             "orc_fr_prefix_product": [_u64p, C.c_size_t, _u64p],
+            "orc_fr_powers": [_u64p, _u64p, C.c_size_t, _u64p],
+            "orc_fr_lincomb": [C.c_uint, C.POINTER(_u64p), _u64p, C.c_size_t, _u64p, C.c_int],
+            "orc_fr_batch_inverse_trick": [_u64p, C.c_size_t, C.c_int],
+            "orc_plonk_perm_terms": [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, _u64p, _u64p, C.c_size_t, _u64p, _u64p,
+                                     C.c_int],
+            "orc_plonk_quotient": [C.POINTER(_u64p), C.c_size_t, _u64p, _u64p, _u64p, _u64p, C.c_int],
         }.items():
             getattr(L, name).restype = None
             getattr(L, name).argtypes = at
@@ -182,6 +188,52 @@ class CpuOracle:
         out = np.empty_like(a)
         if a.shape[0]:
             self.lib.orc_fr_prefix_product(_ptr(a), a.shape[0], _ptr(out))
+        return out
+
+    # ------------------------------------------------- prover rounds
+    @staticmethod
+    def _ptr_array(arrs):
+        keep = [np.ascontiguousarray(a, dtype=np.uint64) for a in arrs]
+        return (_u64p * len(keep))(*[_ptr(a) for a in keep]), keep
+
+    def fr_powers(self, base, scale, n: int) -> np.ndarray:
+        b, sc = (np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (base, scale))
+        out = np.zeros((n, 4), np.uint64)
+        if n:
+            self.lib.orc_fr_powers(_ptr(b), _ptr(sc), n, _ptr(out))
+        return out
+
+    def fr_lincomb(self, coeffs, vecs, threads: int = 1) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        ptrs, keep = self._ptr_array(vecs)
+        n = keep[0].size // 4
+        out = np.zeros((n, 4), np.uint64)
+        self.lib.orc_fr_lincomb(len(keep), ptrs, _ptr(c), n, _ptr(out), threads)
+        return out
+
+    def fr_batch_inverse_trick(self, a, threads: int = 1) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).copy()
+        if a.shape[0]:
+            self.lib.orc_fr_batch_inverse_trick(_ptr(a), a.shape[0], threads)
+        return a
+
+    def plonk_perm_terms(self, wires, sigmas, roots, beta, gamma, threads: int = 1):
+        wp, k1 = self._ptr_array(wires)
+        sp, k2 = self._ptr_array(sigmas)
+        r = np.ascontiguousarray(roots, dtype=np.uint64).reshape(-1, 4)
+        n = r.shape[0]
+        b, g = (np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (beta, gamma))
+        num, den = np.zeros((n, 4), np.uint64), np.zeros((n, 4), np.uint64)
+        self.lib.orc_plonk_perm_terms(wp, sp, _ptr(r), _ptr(b), _ptr(g), n, _ptr(num), _ptr(den), threads)
+        return num, den
+
+    def plonk_quotient(self, arrays18, n: int, alpha, beta, gamma, threads: int = 1) -> np.ndarray:
+        """arrays18: w0..w3, z, q_m, q_l, q_r, q_o, q_4, q_c, pi, s0..s3, l1, x -- each [4n, 4]."""
+        ptrs, keep = self._ptr_array(arrays18)
+        assert len(keep) == 18 and all(a.size == 16 * n for a in keep)
+        a, b, g = (np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (alpha, beta, gamma))
+        out = np.zeros((4 * n, 4), np.uint64)
+        self.lib.orc_plonk_quotient(ptrs, n, _ptr(a), _ptr(b), _ptr(g), _ptr(out), threads)
         return out
 
     # ----------------------------------------------------------------------- G1

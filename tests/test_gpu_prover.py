@@ -330,3 +330,23 @@ def test_gpu_proof_passes_the_pairing_verifier(ctx, oracle, n):
         assert PV.verify(n, vk, swapped, ev, ch, pub_z, tau_g2)[1] is False
         # a proof for a different witness does not verify against tampered public inputs
         assert PV.verify(n, vk, comms, ev, ch, (pub_z + 1) % R, tau_g2)[0] is False
+
+
+@pytest.mark.parametrize("log_n", [10, 14])
+def test_prove_matches_the_c_prover(ctx, oracle, log_n):
+    """Sizes beyond the big-int oracle: every commitment and evaluation of the GPU proof equals the
+    CPU prover composed from the C restatement (oracle/cpu_prover.py), same challenges."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from oracle import cpu_prover as CP
+    n = 1 << log_n
+    circuit, wit, pub = pa.synthetic.chain_circuit(n, 100 + log_n)
+    srs = oracle.g1_bases_arith(ints_to_limbs([0xA5A5], 4)[0], ints_to_limbs([0x7FFFFFFF], 4)[0], n, 8)
+    proof = PR.prove(PR.preprocess(circuit, ctx), pa.CommitKey(srs, ctx, precompute=True), wit, pub)
+    cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
+    exp = CP.prove(oracle, cpk, srs, wit, pub, proof.challenges, threads=8)
+    assert set(exp["commitments"]) == set(proof.commitments) and set(exp["evaluations"]) == set(proof.evaluations)
+    for k, v in exp["evaluations"].items():
+        assert np.array_equal(proof.evaluations[k], v), k
+    for k, v in exp["commitments"].items():
+        assert np.array_equal(proof.commitments[k], v), k

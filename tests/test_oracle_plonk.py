@@ -78,3 +78,28 @@ def test_field_conversions_roundtrip():
     assert np.array_equal(limbs[1], np.array([0x00000001FFFFFFFE, 0x5884B7FA00034802, 0x998C4FEFECBC4FF5,
                                               0x1824B159ACC5056F], dtype=np.uint64))   # R mod r
     assert all(F.fr_from_limbs(F.fr_to_limbs(v)) == v for v in vals)
+
+
+@pytest.mark.parametrize("n", [4, 32])
+def test_c_prover_equals_the_bigint_prover(oracle, n):
+    """The two CPU restatements of the rounds (Python integers; C + OpenMP) agree on every output."""
+    from oracle import cpu_prover as CP
+    from oracle.cpu_oracle import ints_to_limbs, limbs_to_ints
+    from plonk_prototype_amd.synthetic import chain_circuit
+    c, w, pi = chain_circuit(n, 12)
+    sel_l = {k: getattr(c, k) for k in CP.SELECTORS}
+    sel, sigma, wit, pii = _circuit_ints(n, 12)
+    big = PO.prove(n, sel, sigma, wit, pii, CH)
+    srs = oracle.g1_bases_arith(ints_to_limbs([3], 4)[0], ints_to_limbs([11], 4)[0], n, 1)
+    pk = CP.preprocess(oracle, sel_l, c.sigma_index, threads=2)
+    got = CP.prove(oracle, pk, srs, w, pi, CH, threads=2)
+    ev = {k: limbs_to_ints(oracle.fr_from_mont(v.reshape(1, 4)))[0] for k, v in got["evaluations"].items()}
+    assert ev == big["evals"]
+    commit = lambda cf: oracle.g1_msm(srs[:len(cf)], oracle.fr_to_mont(ints_to_limbs(cf, 4)))   # noqa: E731
+    want = {nm: commit(big["wire_coeffs"][j]) for j, nm in enumerate("abcd")}
+    want["z"] = commit(big["z_coeffs"])
+    for i in range(4):
+        want[f"t_{i + 1}"] = commit(big["t_coeffs"][i * n:(i + 1) * n])
+    want["w_z"], want["w_zw"] = commit(big["w_z"]), commit(big["w_zw"])
+    assert set(want) == set(got["commitments"])
+    assert all(np.array_equal(got["commitments"][k], want[k]) for k in want)
