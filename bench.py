@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--no-poly", action="store_true")
     ap.add_argument("--no-prover", action="store_true")
+    ap.add_argument("--no-ntt-extra", action="store_true",
+                    help="skip the PCIe-inclusive and coset-4n NTT measurements (PMC passes: one NTT size only)")
     ap.add_argument("--prover-log-n", type=int, default=20,
                     help="gates of the synthetic circuit for the full-prove entry (BASELINE configs[3])")
     args = ap.parse_args()
@@ -150,7 +152,7 @@ def main():
 
     # ------------------------------------------------------------------ NTT extras (rank 0): SURVEY 8d
     ntt_extra = None
-    if rank == 0:
+    if rank == 0 and not args.no_ntt_extra:
         # (i) the host-pointer ABI call (what a patched dusk-plonk `fft` makes): H2D + NTT + D2H
         ctx.fr_ntt(host_in, k, 0)
         reps = 5

@@ -14,7 +14,7 @@ python tools/pmc_summary.py gpurun_out/$TAG $OUT/pmc_prover_summary.json 20 prv_
 cp $OUT/ntt_traffic.json profiles/ntt_traffic.json && \
 timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err && \
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1 && \
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --no-cpu-baseline --msm-large-log-n 0 --no-poly > $OUT/stats_bench.json 2> $OUT/stats.err)
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --no-cpu-baseline --msm-large-log-n 0 --no-poly --no-ntt-extra > $OUT/stats_bench.json 2> $OUT/stats.err)
 echo "final rc=$?"
 tail -3 $OUT/pytest_gpu.txt
 cat $OUT/smoke.txt
