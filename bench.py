@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--no-poly", action="store_true")
     ap.add_argument("--no-prover", action="store_true")
+    ap.add_argument("--no-msm-extra", action="store_true",
+                    help="skip the witness-like and batched MSM measurements (PMC passes: one MSM shape per mode)")
     ap.add_argument("--no-ntt-extra", action="store_true",
                     help="skip the PCIe-inclusive and coset-4n NTT measurements (PMC passes: one NTT size only)")
     ap.add_argument("--prover-log-n", type=int, default=20,
@@ -225,7 +227,7 @@ def main():
                             "traffic": (json.load(open(tpath)).get(f"msm_accumulate_l1_2^{mk}")
                                         if tpath_exists and world == 1 else None)}}
         assert ok, "MSM result differs from the discrete-log identity"
-        if table and world == 1 and mk <= 20:
+        if table and world == 1 and mk <= 20 and not args.no_msm_extra:
             # "witness-like" scalars: 90 % below 2^16, 5 % zero, 1 % one -- bucket skew and shortcuts
             rs = np.random.default_rng(0x5343414C)
             wl = full_sc.copy()
