@@ -350,3 +350,37 @@ def test_prove_matches_the_c_prover(ctx, oracle, log_n):
         assert np.array_equal(proof.evaluations[k], v), k
     for k, v in exp["commitments"].items():
         assert np.array_equal(proof.commitments[k], v), k
+
+
+def test_round_kernels_empty_and_bad_arguments(ctx, oracle):
+    """n == 0 is a no-op for every entry point; null pointers and bad sizes are reported, not executed."""
+    import ctypes as C
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd import _lib
+    lib, h = ctx._lib, ctx._h
+    one = _mont(oracle, 1)
+    u64p = C.POINTER(C.c_uint64)
+    p1 = one.ctypes.data_as(u64p)
+    v = pa.DeviceVector(ctx, 8)
+    assert lib.pm_fr_powers_dev(h, p1, p1, 0, None, None) == 0
+    assert lib.pm_fr_powers_dev(h, p1, p1, 4, None, None) == -1
+    ptrs = (C.c_void_p * 1)(v._p)
+    assert lib.pm_fr_lincomb_dev(h, 1, ptrs, p1, 0, None, None) == 0
+    assert lib.pm_fr_lincomb_dev(h, 0, ptrs, p1, 4, v._p, None) == -1
+    assert lib.pm_fr_lincomb_dev(h, 1, (C.c_void_p * 1)(None), p1, 4, v._p, None) == -1
+    pargs = _lib.PermArgs()
+    assert lib.pm_plonk_perm_terms_dev(h, C.byref(pargs), 0, None, None, None) == 0
+    assert lib.pm_plonk_perm_terms_dev(h, C.byref(pargs), 4, v._p, v._p, None) == -1     # null wire pointers
+    assert lib.pm_plonk_perm_terms_dev(h, None, 4, v._p, v._p, None) == -1
+    qargs = _lib.QuotientArgs()
+    assert lib.pm_plonk_quotient_dev(h, C.byref(qargs), 0, None, None) == 0
+    assert lib.pm_plonk_quotient_dev(h, C.byref(qargs), 2, v._p, None) == -1             # null operands
+    assert lib.pm_plonk_quotient_dev(h, C.byref(qargs), 3, v._p, None) == -6             # not a power of two
+    G = oracle.g1_generator()
+    assert lib.pm_g1_fixed_base_mul_dev(h, G.ctypes.data_as(u64p), None, 0, 0, None, None) == 0
+    assert lib.pm_g1_fixed_base_mul_dev(h, G.ctypes.data_as(u64p), None, 4, 0, v._p, None) == -1
+    assert lib.pm_g1_fixed_base_mul_dev(h, G.ctypes.data_as(u64p), v._p, 2, 7, v._p, None) == -1   # scalar_form
+    assert b"" != lib.pm_last_error(h)
+    out = C.c_void_p()
+    assert lib.pm_g1_bases_from_dev(h, None, 0, C.byref(out)) == 0 and lib.pm_g1_bases_len(out) == 0
+    lib.pm_g1_bases_free(h, out)
