@@ -386,6 +386,12 @@ def main():
                    "permutation" if name in ("plonk_perm_terms", "fr_batch_inverse", "fr_vec_mul", "fr_prefix_product")
                    else "openings")
             grp[key] += ms
+        q_ms = pprof["plonk_quotient"][1] / pprof["plonk_quotient"][0]
+        q_bytes = 19 * 32 * 4 * gn                      # 18 operands read + 1 result written per coset point
+        q_traffic = None
+        qpath = os.path.join(ROOT, "profiles", "r01_pmc_prover_summary.json")
+        if os.path.exists(qpath) and gk == 20:
+            q_traffic = json.load(open(qpath)).get("pm::quotient_kernel", {}).get("hbm_bytes_per_launch_corrected")
         prover = {"workload": f"full PLONK prove, 2^{gk}-gate synthetic arithmetic circuit (4 wires, copy permutation, "
                               f"1 public input): 5 rounds, 11 commitments, 10 openings, Merlin transcript",
                   "gates": gn, "ms_per_proof": round(pdt * 1e3, 2), "gates_per_s": gn / pdt,
@@ -395,6 +401,11 @@ def main():
                                   f"144-byte partial points all-gathered and folded"),
                   "kernel_ms": {k_: round(v_, 3) for k_, v_ in grp.items()},
                   "kernel_ms_total": round(sum(grp.values()), 2), "preprocess_ms": round(t_pre * 1e3, 1),
+                  "quotient_roofline": {"bound": "hbm", "kernel": "plonk_quotient", "unit": "GB/s",
+                                        "achieved": round(q_bytes / (q_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                        "frac": round(q_bytes / (q_ms * 1e-3) / HBM_PEAK, 4),
+                                        "algorithmic_bytes_per_launch": q_bytes,
+                                        "traffic": int(q_traffic) if q_traffic else None},
                   "verifier_identity_holds": ident_ok, "commitment_matches_dlog": comm_ok,
                   "kzg_opening_equation_holds": kzg_ok, "srs_setup_ms": round(srs_ms, 1) if srs_ms else None,
                   "inputs": "witness and public inputs resident in HBM; proving key and SRS table resident"}
