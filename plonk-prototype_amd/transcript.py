@@ -43,7 +43,12 @@ def keccak_f1600(state: bytearray) -> None:
     global _native
     if _native is None:
         from . import _lib
-        _native = _lib.load().pm_keccak_f1600
+        try:
+            _native = _lib.load().pm_keccak_f1600
+        except _lib.BackendMissing:          # host-only hashing: usable before the HIP library is built
+            _native = False
+    if _native is False:
+        return keccak_f1600_py(state)
     buf = (ctypes.c_char * 200).from_buffer(state)
     _native(buf)
 

@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A clean checkout has no built library (it is git-ignored): build it once so that the ABI /
+    symbol tests have something to load.  hipcc cross-compiles without a GPU (a few minutes)."""
+    lib = os.path.join(ROOT, "plonk-prototype_amd", "lib", "libplonk_mi355x.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "plonk-prototype_amd", "csrc"), "-j3"], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """C CPU restatement (test infrastructure; builds with gcc on first use)."""
