@@ -7,16 +7,20 @@ from oracle import bigint_oracle as B
 from oracle.cpu_oracle import COSET, INVERSE, SCALAR_CANONICAL, SCALAR_MONTGOMERY, ints_to_limbs, limbs_to_ints
 
 pytestmark = pytest.mark.gpu
+# one-off stress runs: PM_FUZZ_SCALE multiplies the number of cases, PM_FUZZ_SEED shifts every seed
+import os  # noqa: E402
+SCALE = int(os.environ.get("PM_FUZZ_SCALE", "1"))
+SEED = int(os.environ.get("PM_FUZZ_SEED", "0"))
 
 
 def test_ntt_random_shapes(ctx, oracle):
-    rng = np.random.default_rng(20261003)
-    for case in range(80):
+    rng = np.random.default_rng(20261003 + SEED)
+    for case in range(80 * SCALE):
         k = int(rng.integers(0, 15))
         n = 1 << k
         in_len = int(rng.integers(0, n + 1))
         flags = int(rng.integers(0, 4))
-        a = oracle.fr_sample(1000 + case, n)[:in_len]
+        a = oracle.fr_sample(1000 + case + 100000 * SEED, n)[:in_len]
         if in_len and rng.random() < 0.3:                      # sparse / structured inputs
             a[rng.integers(0, in_len, size=max(1, in_len // 2))] = 0
         ctx.set_option("ntt_radix", int(rng.choice([4, 8])))
@@ -45,15 +49,15 @@ def test_ntt_extreme_values(ctx, oracle):
 
 def test_msm_random_structure(ctx, oracle):
     import plonk_prototype_amd as pa
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + SEED)
     k0 = ints_to_limbs([0x77777], 4)[0]
     dd = ints_to_limbs([0x123456789abcdef0123], 4)[0]
     pool = oracle.g1_bases_arith(k0, dd, 4096, 8)
     one = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
-    for case in range(40):
+    for case in range(40 * SCALE):
         n = int(rng.integers(1, 3500))
         pts = pool[rng.integers(0, 4096 if rng.random() < 0.6 else 8, size=n)].copy()   # many duplicates sometimes
-        sc = oracle.fr_sample(5000 + case, n)
+        sc = oracle.fr_sample(5000 + case + 100000 * SEED, n)
         mode = case % 5
         if mode == 1:
             sc[rng.random(n) < 0.5] = 0
@@ -122,7 +126,7 @@ def test_prover_round_kernels_random_shapes(ctx, oracle):
     from oracle import plonk_rounds_oracle as PO
     from plonk_prototype_amd import _lib
     R = B.R_MOD
-    rng = random.Random(424242)
+    rng = random.Random(424242 + SEED)
     edge = [0, 1, R - 1, R - 2, (1 << 255) % R, R // 2]
 
     def rand_vec(n):
@@ -137,7 +141,7 @@ def test_prover_round_kernels_random_shapes(ctx, oracle):
     def mont(v):
         return oracle.fr_to_mont(ints_to_limbs([v % R], 4))[0]
 
-    for case in range(25):
+    for case in range(25 * SCALE):
         n = rng.randrange(1, 2500)
         base, scale = rng.choice(edge + [rng.randrange(R)]), rng.choice(edge + [rng.randrange(R)])
         out = pa.DeviceVector(ctx, n)
