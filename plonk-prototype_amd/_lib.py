@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplonk_mi355x.so")
+# PM_LIB_PATH: load another build of the same library (A/B runs of compiler flags)
+LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "lib", "libplonk_mi355x.so")
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
