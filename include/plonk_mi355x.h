@@ -173,7 +173,7 @@ int pm_fr_vec_op_dev(pm_ctx* ctx, int op, const void* d_a, const void* d_b, size
 int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t point[4],
                             uint64_t out[4], void* hip_stream);
 /* Polynomial::ruffini: quotient of coeffs(X) / (X - z), n-1 coefficients into d_out (the
- * remainder coeffs(z) is dropped, as upstream).  Not in place.  Returns after the work finished. */
+ * remainder coeffs(z) is dropped, as upstream).  Not in place.  Asynchronous on the stream. */
 int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], void* d_out,
                            void* hip_stream);
 /* out[0] = 1, out[i] = in[0] * ... * in[i-1]: the grand-product accumulator z(X) of the permutation

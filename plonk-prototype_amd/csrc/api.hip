@@ -119,7 +119,7 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
     }
   }
   for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws,
-                          &ctx->msm_scalars, &ctx->poly_ws})
+                          &ctx->msm_scalars, &ctx->poly_ws, &ctx->poly_tab})
     if (b->ptr) hipFree(b->ptr);
   if (ctx->msm_host_pinned) hipHostFree(ctx->msm_host_pinned);
   prof_collect(ctx);

@@ -43,6 +43,7 @@ struct pm_ctx {
   pm::DeviceBuffer msm_ws;
   pm::DeviceBuffer msm_scalars;
   pm::DeviceBuffer poly_ws;                             // scratch of the polynomial helpers
+  pm::DeviceBuffer poly_tab;                            // power tables of pm_fr_poly_ruffini_dev
   void* msm_host_pinned = nullptr;
   size_t msm_host_pinned_bytes = 0;
   // opt-in per-kernel timing (hipEvents on the launch stream; read by bench.py)

@@ -377,16 +377,14 @@ __global__ void __launch_bounds__(256) prefix_prod_final_kernel(const u32x4* tmp
 }
 
 // ------------------------------------------------------------------ host helpers
-static int build_pow(pm_ctx* ctx, void** out, const HFr& base, u32 count, u32 stride, hipStream_t st) {
-  PM_HIP(ctx, hipMalloc(out, (size_t)count * 48));
+// out[i] = base^(i * stride), `count` device-form entries of 48 bytes at `out` (caller-provided memory)
+static void build_pow(u32x4* out, const HFr& base, u32 count, u32 stride, hipStream_t st) {
   NttConsts c;
   memset(&c, 0, sizeof c);
   to_limbs29(c.w8[0], base);
   to_limbs29(c.scale, host::one(host::FR()));
   to_limbs29(c.one, host::one(host::FR()));
-  hipLaunchKernelGGL(pow_table_kernel, dim3((count + 255) / 256), dim3(256), 0, st, (u32x4*)*out, c, count, stride);
-  PM_HIP(ctx, hipGetLastError());
-  return PM_OK;
+  hipLaunchKernelGGL(pow_table_kernel, dim3((count + 255) / 256), dim3(256), 0, st, out, c, count, stride);
 }
 
 }  // namespace pm
@@ -519,36 +517,37 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   const u32 lh = (lg + 1) / 2, n_lo = 1u << lh, n_hi = (u32)((m >> lh) + 1);
   const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(16, m / ((size_t)256 * 1024)));
   const u32 nblocks = (u32)((m + (size_t)256 * L - 1) / ((size_t)256 * L));
-  void *zi_hi = nullptr, *zi_lo = nullptr, *z_hi = nullptr, *z_lo = nullptr;
+  // the four power tables live in a context buffer: no allocator calls (and no device-wide
+  // synchronisation from hipFree) inside a proving loop
   HFr zinv = host::inv(zz, F);
-  int rc = build_pow(ctx, &zi_lo, zinv, n_lo, 1, st);
-  if (!rc) rc = build_pow(ctx, &zi_hi, zinv, n_hi, n_lo, st);
-  if (!rc) rc = build_pow(ctx, &z_lo, zz, n_lo, 1, st);
-  if (!rc) rc = build_pow(ctx, &z_hi, zz, n_hi, n_lo, st);
+  const size_t tab_entries = 2 * ((size_t)n_lo + n_hi);
+  int rc = ensure_buffer(ctx, ctx->poly_tab, tab_entries * 48);
   if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, m * 32 + (size_t)nblocks * 48 + 64);
-  if (!rc) {
-    ScanArgs a;
-    a.coeffs = (const u32x4*)d_coeffs;
-    a.tmp = (u32x4*)ctx->poly_ws.ptr;
-    a.block_tot = a.tmp + 2 * m;
-    a.zi_hi = (const u32x4*)zi_hi;
-    a.zi_lo = (const u32x4*)zi_lo;
-    a.z_hi = (const u32x4*)z_hi;
-    a.z_lo = (const u32x4*)z_lo;
-    a.out = (u32x4*)d_out;
-    a.n = n;
-    a.lh = lh;
-    a.L = L;
-    ProfScope prof(ctx, st, "fr_poly_ruffini");
-    hipLaunchKernelGGL(ruffini_local_kernel, dim3(nblocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ruffini_carry_kernel, dim3(1), dim3(256), 0, st, a.block_tot, nblocks);
-    hipLaunchKernelGGL(ruffini_final_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
-    if (hipGetLastError() != hipSuccess) rc = set_err(ctx, PM_ERR_HIP, "ruffini launch failed");
-  }
-  (void)hipStreamSynchronize(st);  // the power tables are freed below
-  for (void* p : {zi_hi, zi_lo, z_hi, z_lo})
-    if (p) (void)hipFree(p);
-  return rc;
+  if (rc) return rc;
+  u32x4* tab = (u32x4*)ctx->poly_tab.ptr;
+  u32x4 *zi_lo = tab, *zi_hi = zi_lo + 3 * (size_t)n_lo, *z_lo = zi_hi + 3 * (size_t)n_hi, *z_hi = z_lo + 3 * (size_t)n_lo;
+  build_pow(zi_lo, zinv, n_lo, 1, st);
+  build_pow(zi_hi, zinv, n_hi, n_lo, st);
+  build_pow(z_lo, zz, n_lo, 1, st);
+  build_pow(z_hi, zz, n_hi, n_lo, st);
+  ScanArgs a;
+  a.coeffs = (const u32x4*)d_coeffs;
+  a.tmp = (u32x4*)ctx->poly_ws.ptr;
+  a.block_tot = a.tmp + 2 * m;
+  a.zi_hi = zi_hi;
+  a.zi_lo = zi_lo;
+  a.z_hi = z_hi;
+  a.z_lo = z_lo;
+  a.out = (u32x4*)d_out;
+  a.n = n;
+  a.lh = lh;
+  a.L = L;
+  ProfScope prof(ctx, st, "fr_poly_ruffini");
+  hipLaunchKernelGGL(ruffini_local_kernel, dim3(nblocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ruffini_carry_kernel, dim3(1), dim3(256), 0, st, a.block_tot, nblocks);
+  hipLaunchKernelGGL(ruffini_final_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
 }
 
 extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n, void* d_out, void* hip_stream) {

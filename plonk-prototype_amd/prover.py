@@ -227,9 +227,11 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, transcript:
     pi_coeffs = coeffs.ptr + 32 * 5 * n
     if isinstance(public_inputs, DeviceVector):
         pi_ev, own_pi = public_inputs, False
+    elif public_inputs is None:                                    # PI = 0: a device-side fill, no upload
+        pi_ev, own_pi = pk.workspace("pi_zero", n), False
+        ctx.fr_powers(fr(0), fr(0), n, pi_ev.ptr)
     else:
-        pi_host = np.zeros((n, 4), np.uint64) if public_inputs is None else \
-            np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(n, 4)
+        pi_host = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(n, 4)
         pi_ev, own_pi = DeviceVector.from_host(ctx, pi_host), True
     ctx.fr_ntt_dev(pi_ev.ptr, n, pi_coeffs, log_n, _lib.NTT_INVERSE)
     coset = pk.workspace("coset", 6 * 4 * n)                         # a, b, c, d, z, pi on the 4n coset
