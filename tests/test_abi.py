@@ -105,3 +105,14 @@ def test_fold_and_to_affine_on_host(oracle):
                              oracle.fp_mul(pts[1][6:].reshape(1, 6), z7)[0], z7[0]])
     assert np.array_equal(pa.g1_to_affine(scaled)[0], pts[1])
     assert np.array_equal(oracle.g1_projective_to_affine(scaled), pts[1])
+
+
+def test_integration_doc_lists_every_export():
+    """INTEGRATION.md's Rust extern block binds exactly the functions the header declares."""
+    import re
+    from conftest import ROOT
+    header = open(os.path.join(ROOT, "include", "plonk_mi355x.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    exports = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (pm_[a-z0-9_]+)", doc))
+    assert exports == bound, (sorted(exports - bound), sorted(bound - exports))
