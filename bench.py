@@ -113,10 +113,19 @@ def main():
         ctx.fr_ntt_dev(d_a.data_ptr(), n, d_b.data_ptr(), k, 0, stream=stream)
         ctx.fr_ntt_dev(d_b.data_ptr(), n, d_c.data_ptr(), k, INVERSE, stream=stream)
 
-    for _ in range(args.warmup):
-        step()
+    # warm-up doubles as a fully profiled pre-run: it names the dominant kernel and gives every kernel's
+    # mean duration; the timed region then keeps the event pair of the dominant kernel only (an event
+    # pair is ~5 us of stream time, and the roofline needs that one kernel's live duration)
+    step()                                                          # first launches: tables, code load
     barrier()
     ctx.profile(True)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    pre = {name: v for name, v in ctx.profile_read().items() if name.startswith("ntt_pass")}
+    dom = max(pre, key=lambda s_: pre[s_][1])
+    ctx.profile(True, only=dom)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -130,8 +139,8 @@ def main():
 
     # roofline of the dominant kernel: algorithmic bytes of one launch / its mean duration
     passes = pa.ntt_plan(k)
-    kern = {name: (cnt, ms) for name, (cnt, ms) in prof.items() if name.startswith("ntt_pass")}
-    dom = max(kern, key=lambda s: kern[s][1])
+    kern = dict(pre)
+    kern[dom] = prof[dom]                                          # live, over the timed region
     dom_ms = kern[dom][1] / kern[dom][0]
     s_dom = passes[0] if dom.endswith("first") or dom.endswith("single") else passes[-1]
     algo_bytes = 64 * n * s_dom / k                                # 64 N bytes per transform, S/k of it per pass

@@ -253,6 +253,9 @@ int pm_set_option(pm_ctx* ctx, const char* key, long value);
 /* Opt-in per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline
  * leg).  pm_profile_read writes lines "<kernel> <launches> <total_ms>\n" into buf. */
 int pm_profile_enable(pm_ctx* ctx, int on);
+/* Restrict the timers to one kernel name (as printed by pm_profile_read), NULL = all: an event pair
+ * costs ~5 us of launch stream time, so a timed region that needs one kernel's duration asks for that one. */
+int pm_profile_select(pm_ctx* ctx, const char* kernel_name);
 int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap);
 /* Elementwise field kernels used by the parity tests: op 0 = Fr mul, 1 = Fr add, 2 = Fr sub,
  * 3 = Fp mul, 4 = Fp add, 5 = Fp sub.  Host pointers, n elements. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     "pm_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pm_profile_select": (C.c_int, [C.c_void_p, C.c_char_p]),
     "pm_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "pm_test_field_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
 }

@@ -39,6 +39,7 @@ static hipEvent_t prof_event(pm_ctx* ctx) {
 }
 ProfScope::ProfScope(pm_ctx* c, hipStream_t s, const char* name) : ctx(c), st(s) {
   if (!ctx->profile) return;
+  if (!ctx->profile_only.empty() && ctx->profile_only != name) return;
   hipEvent_t a = prof_event(ctx);
   stop = prof_event(ctx);
   (void)hipEventRecord(a, st);
@@ -154,6 +155,13 @@ extern "C" int pm_profile_enable(pm_ctx* ctx, int on) {
       ctx->prof_pool.push_back(e);
     }
   }
+  return PM_OK;
+}
+
+extern "C" int pm_profile_select(pm_ctx* ctx, const char* kernel_name) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->profile_only = kernel_name ? kernel_name : "";
   return PM_OK;
 }
 

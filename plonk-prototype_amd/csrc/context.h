@@ -48,6 +48,7 @@ struct pm_ctx {
   size_t msm_host_pinned_bytes = 0;
   // opt-in per-kernel timing (hipEvents on the launch stream; read by bench.py)
   bool profile = false;
+  std::string profile_only;      // when set, only scopes with exactly this name record events
   struct ProfPending {
     hipEvent_t start, stop;
     const char* name;

@@ -75,7 +75,9 @@ class Context:
     def set_option(self, key: str, value: int):
         self._check(self._lib.pm_set_option(self._h, key.encode(), int(value)))
 
-    def profile(self, on: bool):
+    def profile(self, on: bool, only: str | None = None):
+        """Per-kernel event timers; `only` restricts them to one kernel name (less launch overhead)."""
+        self._check(self._lib.pm_profile_select(self._h, only.encode() if only else None))
         self._check(self._lib.pm_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self) -> dict:
