@@ -34,7 +34,7 @@ static hipEvent_t prof_event(pm_ctx* ctx) {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);   // timing only: no system-scope fence per record
   return e;
 }
 ProfScope::ProfScope(pm_ctx* c, hipStream_t s, const char* name) : ctx(c), st(s) {
@@ -151,7 +151,7 @@ extern "C" int pm_profile_enable(pm_ctx* ctx, int on) {
     // between two kernels of the region being timed
     while (ctx->prof_pool.size() < 4096) {
       hipEvent_t e = nullptr;
-      if (hipEventCreate(&e) != hipSuccess) break;
+      if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break;
       ctx->prof_pool.push_back(e);
     }
   }
