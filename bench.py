@@ -183,7 +183,27 @@ def main():
             ctx.fr_ntt_dev(d_a.data_ptr(), n, d4.data_ptr(), k + 2, pa.NTT_COSET, stream=stream)
         local_sync()
         c4 = (time.perf_counter() - t0) / 20
-        ntt_extra = {"pcie_inclusive": {"ms_per_transform": round(e2e * 1e3, 3), "butterflies_per_s": (n // 2) * k / e2e,
+        # (iii) the metric's second size: forward + inverse at 2^24, device resident
+        big = None
+        if k < 24:
+            kb, nb = 24, 1 << 24
+            xb = torch.from_numpy(oracle.fr_sample(0x504C4F4E4C, nb).view(np.int64)).to(dev)
+            yb, zb = torch.empty_like(xb), torch.empty_like(xb)
+            for _ in range(2):
+                ctx.fr_ntt_dev(xb.data_ptr(), nb, yb.data_ptr(), kb, 0, stream=stream)
+                ctx.fr_ntt_dev(yb.data_ptr(), nb, zb.data_ptr(), kb, INVERSE, stream=stream)
+            local_sync()
+            assert torch.equal(xb, zb), "iNTT(NTT(a)) != a at 2^24"
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ctx.fr_ntt_dev(xb.data_ptr(), nb, yb.data_ptr(), kb, 0, stream=stream)
+                ctx.fr_ntt_dev(yb.data_ptr(), nb, zb.data_ptr(), kb, INVERSE, stream=stream)
+            local_sync()
+            tb = (time.perf_counter() - t0) / 10
+            big = {"log_n": kb, "ms_per_step": round(tb * 1e3, 3), "butterflies_per_s": nb * kb / tb,
+                   "passes": pa.ntt_plan(kb)}
+            del xb, yb, zb
+        ntt_extra = {"fwd_inv_2^24": big, "pcie_inclusive": {"ms_per_transform": round(e2e * 1e3, 3), "butterflies_per_s": (n // 2) * k / e2e,
                                         "note": "pm_fr_ntt with pageable host buffers: H2D + transform + D2H; never `value`"},
                      "coset_4n": {"log_n": k + 2, "in_len": n, "us_per_transform": round(c4 * 1e6, 1),
                                   "butterflies_per_s": (2 * n) * (k + 2) / c4}}
