@@ -248,7 +248,8 @@ void pm_keccak_f1600(uint8_t state[200]);
 
 /* Number of kernel launches and the Stockham radices the library will use for 2^log_n. */
 int pm_ntt_plan(uint32_t log_n, uint32_t radix_log2[4], uint32_t* n_passes);
-/* Override tunables: "msm_window_bits", "ntt_tile_log".  Returns PM_ERR_BAD_ARG if unknown. */
+/* Override tunables: "msm_window_bits", "ntt_tile_log", "ntt_pipeline" (0 = no copy / compute overlap in
+ * pm_fr_ntt_batch), ...  Returns PM_ERR_BAD_ARG if unknown. */
 int pm_set_option(pm_ctx* ctx, const char* key, long value);
 /* Opt-in per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline
  * leg).  pm_profile_read writes lines "<kernel> <launches> <total_ms>\n" into buf. */

@@ -125,6 +125,8 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
   if (ctx->msm_host_pinned) hipHostFree(ctx->msm_host_pinned);
   prof_collect(ctx);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+  if (ctx->copy_in) hipStreamDestroy(ctx->copy_in);
+  if (ctx->copy_out) hipStreamDestroy(ctx->copy_out);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -201,6 +203,10 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
   }
   if (!strcmp(key, "ntt_xcd")) {
     ctx->opt_ntt_xcd = value != 0;
+    return PM_OK;
+  }
+  if (!strcmp(key, "ntt_pipeline")) {
+    ctx->opt_ntt_pipeline = value != 0;
     return PM_OK;
   }
   if (!strcmp(key, "ntt_radix")) {

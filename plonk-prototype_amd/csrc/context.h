@@ -31,6 +31,7 @@ struct NttDomainTables {  // per (log_n, direction)
 struct pm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_in = nullptr, copy_out = nullptr;    // host-pointer batch calls: H2D / D2H beside the compute stream
   std::mutex mu;
   std::string err;
   // NTT caches
@@ -65,6 +66,7 @@ struct pm_ctx {
   long opt_ntt_tile_log = 0;     // 0 = auto
   long opt_ntt_radix = 4;        // in-tile butterfly radix: 4 (4 elements per thread) or 8
   long opt_ntt_xcd = 1;          // XCD-aware blockIdx -> tile mapping
+  long opt_ntt_pipeline = 1;     // host-pointer batch calls: overlap H2D / transform / D2H per vector
   long opt_ntt_max_radix = 10;   // log2 of the largest pass radix (multi-pass plans)
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)

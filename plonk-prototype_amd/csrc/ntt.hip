@@ -4,6 +4,9 @@
 //   fft/ifft/coset_fft/coset_ifft -> ntt_run() with PM_NTT_INVERSE / PM_NTT_COSET
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
+#include <thread>
+
 #include <algorithm>
 #include <cstring>
 
@@ -417,14 +420,82 @@ extern "C" int pm_fr_ntt_batch(pm_ctx* ctx, const uint64_t* in, size_t in_len, s
   if (rc) return rc;
   rc = ensure_buffer(ctx, ctx->io_out, (size_t)batch * n * 32);
   if (rc) return rc;
-  if (in_len)
-    PM_HIP(ctx, hipMemcpy2DAsync(ctx->io_in.ptr, in_elems * 32, in, in_stride * 32, in_len * 32,
-                                 batch, hipMemcpyHostToDevice, st));
-  rc = ntt_run(ctx, ctx->io_in.ptr, in_len, in_elems, ctx->io_out.ptr, n, log_n, batch, flags, st);
+  if (batch == 1 || ctx->opt_ntt_pipeline == 0) {
+    if (in_len)
+      PM_HIP(ctx, hipMemcpy2DAsync(ctx->io_in.ptr, in_elems * 32, in, in_stride * 32, in_len * 32,
+                                   batch, hipMemcpyHostToDevice, st));
+    rc = ntt_run(ctx, ctx->io_in.ptr, in_len, in_elems, ctx->io_out.ptr, n, log_n, batch, flags, st);
+    if (rc) return rc;
+    PM_HIP(ctx, hipMemcpy2DAsync(out, out_stride * 32, ctx->io_out.ptr, n * 32, n * 32, batch,
+                                 hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    return PM_OK;
+  }
+  // Several polynomials from host memory (a prover round): the transfers are 10-30x the transform, so
+  // they are what gets overlapped.  PCIe is full duplex: vector b+1 goes up on `copy_in` while vector b
+  // is transformed on the compute stream and vector b-1 comes down on `copy_out`.  Copies from pageable
+  // memory block the calling thread, hence the downloads run on a helper thread.
+  if (!ctx->copy_in) PM_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+  if (!ctx->copy_out) PM_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+  std::vector<hipEvent_t> ev_in(batch), ev_done(batch);
+  for (uint32_t b = 0; b < batch; ++b) {
+    PM_HIP(ctx, hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
+    PM_HIP(ctx, hipEventCreateWithFlags(&ev_done[b], hipEventDisableTiming));
+  }
+  std::mutex mq;
+  std::condition_variable cv;
+  uint32_t launched = 0;          // vectors whose transform has been enqueued (guarded by mq)
+  bool abort_all = false;
+  hipError_t down_err = hipSuccess;
+  std::thread downloader([&] {
+    (void)hipSetDevice(ctx->device);
+    for (uint32_t b = 0; b < batch; ++b) {
+      {
+        std::unique_lock<std::mutex> lk2(mq);
+        cv.wait(lk2, [&] { return launched > b || abort_all; });
+        if (abort_all) return;
+      }
+      hipError_t e = hipStreamWaitEvent(ctx->copy_out, ev_done[b], 0);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(out + 4 * (size_t)b * out_stride, (const char*)ctx->io_out.ptr + (size_t)b * n * 32, n * 32,
+                           hipMemcpyDeviceToHost, ctx->copy_out);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_out);
+      if (e != hipSuccess) {
+        down_err = e;
+        return;
+      }
+    }
+  });
+  hipError_t up_err = hipSuccess;
+  for (uint32_t b = 0; b < batch && !rc && up_err == hipSuccess; ++b) {
+    char* d_in_b = (char*)ctx->io_in.ptr + (size_t)b * in_elems * 32;
+    if (in_len) up_err = hipMemcpyAsync(d_in_b, in + 4 * (size_t)b * in_stride, in_len * 32, hipMemcpyHostToDevice, ctx->copy_in);
+    if (up_err == hipSuccess) up_err = hipEventRecord(ev_in[b], ctx->copy_in);
+    if (up_err == hipSuccess) up_err = hipStreamWaitEvent(st, ev_in[b], 0);
+    if (up_err != hipSuccess) break;
+    rc = ntt_run(ctx, d_in_b, in_len, in_elems, (char*)ctx->io_out.ptr + (size_t)b * n * 32, n, log_n, 1, flags, st);
+    if (rc) break;
+    up_err = hipEventRecord(ev_done[b], st);
+    {
+      std::lock_guard<std::mutex> lk2(mq);
+      launched = b + 1;
+    }
+    cv.notify_one();
+  }
+  if (rc || up_err != hipSuccess) {
+    std::lock_guard<std::mutex> lk2(mq);
+    abort_all = true;
+  }
+  cv.notify_one();
+  downloader.join();
+  (void)hipStreamSynchronize(st);
+  for (uint32_t b = 0; b < batch; ++b) {
+    (void)hipEventDestroy(ev_in[b]);
+    (void)hipEventDestroy(ev_done[b]);
+  }
   if (rc) return rc;
-  PM_HIP(ctx, hipMemcpy2DAsync(out, out_stride * 32, ctx->io_out.ptr, n * 32, n * 32, batch,
-                               hipMemcpyDeviceToHost, st));
-  PM_HIP(ctx, hipStreamSynchronize(st));
+  if (up_err != hipSuccess || down_err != hipSuccess)
+    return set_err(ctx, PM_ERR_HIP, std::string("pipelined batch NTT: ") + hipGetErrorString(up_err != hipSuccess ? up_err : down_err));
   return PM_OK;
 }
 

@@ -100,12 +100,13 @@ class Context:
         self._check(self._lib.pm_fr_ntt(self._h, _p(src), a.shape[0], _p(out), log_n, flags))
         return out
 
-    def fr_ntt_batch(self, a, log_n: int, flags: int = 0) -> np.ndarray:
-        """a: [batch, in_len, 4] -> [batch, 2^log_n, 4]."""
+    def fr_ntt_batch(self, a, log_n: int, flags: int = 0, out=None) -> np.ndarray:
+        """a: [batch, in_len, 4] -> [batch, 2^log_n, 4] (into `out` when given)."""
         a = np.ascontiguousarray(a, dtype=np.uint64)
         batch, in_len = a.shape[0], a.shape[1]
         n = 1 << log_n
-        out = np.empty((batch, n, 4), dtype=np.uint64)
+        if out is None:
+            out = np.empty((batch, n, 4), dtype=np.uint64)
         self._check(self._lib.pm_fr_ntt_batch(self._h, _p(a), in_len, in_len, _p(out), n, log_n,
                                               batch, flags))
         return out

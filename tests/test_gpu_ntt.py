@@ -166,3 +166,21 @@ def test_full_size_properties(ctx, oracle, k):
     lhs = ctx.fr_ntt(ab, k, 0)[idx]
     rhs = ctx.field_op(1, np.ascontiguousarray(f[idx]), np.ascontiguousarray(ctx.fr_ntt(b, k, 0)[idx]))
     assert np.array_equal(lhs, rhs)
+
+
+@pytest.mark.parametrize("log_n,batch,in_len", [(10, 2, 1024), (12, 5, 3000), (16, 3, 65536), (3, 4, 8)])
+def test_host_batch_pipeline_matches_the_serial_path(ctx, oracle, log_n, batch, in_len):
+    """pm_fr_ntt_batch overlaps upload / transform / download per vector on three streams; the result
+    must equal the serial path (option ntt_pipeline = 0) and the oracle, for every flag combination."""
+    a = np.stack([oracle.fr_sample(700 + 10 * log_n + b, in_len) for b in range(batch)])
+    for flags in (0, 1, 2, 3):
+        ctx.set_option("ntt_pipeline", 1)
+        piped = ctx.fr_ntt_batch(a, log_n, flags)
+        ctx.set_option("ntt_pipeline", 0)
+        try:
+            serial = ctx.fr_ntt_batch(a, log_n, flags)
+        finally:
+            ctx.set_option("ntt_pipeline", 1)
+        assert np.array_equal(piped, serial)
+        for b in range(batch):
+            assert np.array_equal(piped[b], oracle.fr_ntt(a[b], log_n, flags, 4)), (flags, b)
