@@ -1,0 +1,100 @@
+// The C++ host mirror (include/plonk_mi355x.hpp) used the way the reference's Rust code uses
+// dusk-plonk: EvaluationDomain, msm_variable_base, CommitKey, Polynomial -- no Python in the process.
+//   g++ -std=c++17 -O2 examples/host_demo.cpp -Iinclude -Lplonk-prototype_amd/lib -lplonk_mi355x
+//       -Wl,-rpath,$PWD/plonk-prototype_amd/lib -o host_demo && ./host_demo     (one command line)
+// Exit code 0 and "host_demo OK" on success; without a gfx950 device it reports the Error and exits 1.
+#include <cstdio>
+#include <cstring>
+
+#include "plonk_mi355x.hpp"
+
+using namespace plonk_mi355x;
+
+static uint64_t rng_state = 0x243F6A8885A308D3ULL;
+static uint64_t next_u64() {
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static Fr random_fr() {
+  Fr r{next_u64(), next_u64(), next_u64(), next_u64() & ((1ULL << 62) - 1)};   // < 2^254 < r
+  return r;
+}
+static const G1Affine G1_GEN = {0x5cb38790fd530c16ULL, 0x7817fc679976fff5ULL, 0x154f95c7143ba1c1ULL,
+                                0xf0ae6acdf3d0e747ULL, 0xedce6ecc21dbf440ULL, 0x120177419e0bfb75ULL,
+                                0xbaac93d50ce72271ULL, 0x8c22631a7918fd8eULL, 0xdd595f13570725ceULL,
+                                0x51ac582950405194ULL, 0x0e1c8c3fad0059c0ULL, 0x0bbc3efc5008a26aULL};
+#define REQUIRE(cond)                                              \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      std::fprintf(stderr, "host_demo: failed: %s\n", #cond);      \
+      return 1;                                                    \
+    }                                                              \
+  } while (0)
+
+int main() {
+  try {
+    Context ctx(0);
+    // ---- EvaluationDomain ---------------------------------------------------------------------
+    EvaluationDomain dom(ctx, 1000);
+    REQUIRE(dom.size == 1024 && dom.log_size_of_group == 10);
+    std::vector<Fr> a(1000), b(1000);
+    for (auto& x : a) x = random_fr();
+    for (auto& x : b) x = random_fr();
+    std::vector<Fr> padded = a;
+    padded.resize(1024, Fr{0, 0, 0, 0});
+    REQUIRE(dom.ifft(dom.fft(a)) == padded);
+    REQUIRE(dom.coset_ifft(dom.coset_fft(a)) == padded);
+    std::vector<Fr> inplace = a;
+    dom.fft_in_place(inplace);
+    REQUIRE(inplace == dom.fft(a));
+    std::vector<Fr> el = dom.elements();
+    REQUIRE(el[0] == EvaluationDomain::one() && el[1] == dom.group_gen);
+    auto many = dom.fft_many({a, b, a}, PM_NTT_COSET);
+    REQUIRE(many.size() == 3 && many[0] == dom.coset_fft(a) && many[1] == dom.coset_fft(b) && many[2] == many[0]);
+    bool threw = false;
+    try { EvaluationDomain too_big(ctx, (size_t)1 << 33); } catch (const Error& e) { threw = e.code == PM_ERR_DOMAIN_TOO_LARGE; }
+    REQUIRE(threw);                                        // InvalidEvalDomainSize
+    threw = false;
+    try { dom.fft(std::vector<Fr>(1025, Fr{1, 0, 0, 0})); } catch (const Error& e) { threw = e.code == PM_ERR_LENGTH; }
+    REQUIRE(threw);
+    // linearity, with the sum formed on the device: fft(a) + fft(b) == fft(a + b)
+    DevicePolynomial da(ctx, a), db(ctx, b);
+    REQUIRE(DevicePolynomial(ctx, dom.fft(a)).add(DevicePolynomial(ctx, dom.fft(b))).to_host() == dom.fft(da.add(db).to_host()));
+    REQUIRE(da.ntt(10, 0).to_host() == dom.fft(a));        // the device-resident transform is the same transform
+
+    // ---- msm_variable_base / CommitKey ----------------------------------------------------------
+    const size_t m = 600;
+    std::vector<G1Affine> pts(m, G1_GEN);
+    std::vector<Fr> sc(a.begin(), a.begin() + m);
+    CommitKey ck(ctx, pts, /*precompute=*/true);
+    REQUIRE(ck.max_degree() == m - 1);
+    G1Affine c1 = ck.commit(sc);
+    REQUIRE(c1 == to_affine(msm_variable_base(ctx, pts, sc)));
+    // all bases equal G: commit(s) = (sum s_i) G = commit of the one-term polynomial [p(1)]
+    DevicePolynomial dsc(ctx, sc);
+    Fr sum = dsc.evaluate(EvaluationDomain::one());
+    REQUIRE(c1 == ck.commit({sum}));
+    REQUIRE(dsc.commit(ck) == c1);
+    bool ident = false;
+    to_affine(msm_variable_base(ctx, {}, {}), &ident);
+    REQUIRE(ident);                                        // the empty sum is the identity
+    threw = false;
+    try { ck.commit(std::vector<Fr>(m + 1, Fr{0, 0, 0, 0})); } catch (const Error& e) { threw = e.code == PM_ERR_LENGTH; }
+    REQUIRE(threw);                                        // PolynomialDegreeTooLarge
+
+    // ---- Polynomial: p(X) - p(z) = q(X) (X - z) at a random point, all on the device --------------
+    Fr z = random_fr(), x = random_fr();
+    DevicePolynomial q = da.ruffini(z);
+    REQUIRE(q.len() == a.size() - 1);
+    DevicePolynomial px(ctx, std::vector<Fr>{da.evaluate(x)}), pz(ctx, std::vector<Fr>{da.evaluate(z)});
+    DevicePolynomial qx(ctx, std::vector<Fr>{q.evaluate(x)}), dx(ctx, std::vector<Fr>{x}), dz(ctx, std::vector<Fr>{z});
+    REQUIRE(px.sub(pz).to_host() == qx.mul(dx.sub(dz)).to_host());
+    std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial over %s)\n", pm_version());
+    return 0;
+  } catch (const Error& e) {
+    std::fprintf(stderr, "plonk_mi355x::Error %d: %s\n", e.code, e.what());
+    return 1;
+  }
+}

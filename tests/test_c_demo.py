@@ -1,6 +1,7 @@
-"""examples/abi_demo.c: the C ABI used from plain C (no Python, no torch in the process).
-CPU: it compiles against include/plonk_mi355x.h, links against the built library and fails loudly
-without a device.  GPU: it runs its NTT / MSM checks."""
+"""examples/abi_demo.c: the C ABI used from plain C, and examples/host_demo.cpp: the C++ host mirror
+of the dusk interface (include/plonk_mi355x.hpp) -- no Python, no torch in the process.
+CPU: they compile, link against the built library and fail loudly without a device.
+GPU: they run their NTT / MSM / polynomial checks."""
 import os
 import subprocess
 
@@ -36,3 +37,26 @@ def test_c_demo_runs_on_the_gpu(tmp_path, log_n):
     r = subprocess.run([exe, str(log_n)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "abi_demo OK" in r.stdout
+
+
+def _build_cpp(tmp_path):
+    exe = str(tmp_path / "host_demo")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "host_demo.cpp"),
+           "-I", os.path.join(ROOT, "include"), "-L", LIBDIR, "-lplonk_mi355x", f"-Wl,-rpath,{LIBDIR}", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the gpu-marked test runs the demo")
+    r = subprocess.run([_build_cpp(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Error -5" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_runs_on_the_gpu(tmp_path):
+    r = subprocess.run([_build_cpp(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "host_demo OK" in r.stdout
