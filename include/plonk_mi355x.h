@@ -240,6 +240,30 @@ typedef struct pm_plonk_quotient_args {
 int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, void* d_out,
                           void* hip_stream);
 
+/* ---- the whole prover behind one call ------------------------------------------------------------ */
+/* Prover::prove_with_preprocessed (dusk-plonk 0.8.2, ref:Cargo.toml:19) for the arithmetic gate and the
+ * 4-wire permutation, sequenced inside the library: five rounds, 11 commitments, 10 evaluations, Merlin
+ * transcript (labels: "w_a".."w_d", "beta", "gamma", "z", "alpha", "t_1".."t_4", "z", "<name>_eval", "v",
+ * "w_z", "w_zw", "u" -- upstream's label strings are not available here).  plonk-prototype_amd/prover.py is
+ * the same sequence in Python; the two produce identical proofs. */
+typedef struct pm_prover_key pm_prover_key;
+typedef struct pm_plonk_proof {
+  uint64_t commitments[11][12];  /* a b c d z t_1 t_2 t_3 t_4 w_z w_zw, affine, (0, 0) = identity */
+  uint64_t evaluations[10][4];   /* a b c d sigma_1 sigma_2 sigma_3 z_next t r, Montgomery limbs */
+  uint64_t challenges[6][4];     /* beta gamma alpha z v u (recomputable from the transcript) */
+} pm_plonk_proof;
+/* ProverKey: selectors[s] = n evaluations on H of q_m q_l q_r q_o q_4 q_c (host memory); sigma_index[j n + i] =
+ * position (j' n + i') that follows wire j of gate i in its copy cycle.  n a power of two >= 4.  Builds
+ * the coefficient and 4n-coset forms on the device and the per-proof workspace (about 90 n x 32 bytes). */
+int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[6], const int64_t* sigma_index, size_t n,
+                        pm_prover_key** out);
+void pm_plonk_key_free(pm_ctx* ctx, pm_prover_key* key);
+/* d_witness: device memory, [a | b | c | d] wire values, 4n Fr.  d_public_inputs: device memory, n
+ * evaluations of PI on H, or NULL for none.  commit_key: at least n resident bases (pm_g1_bases_upload /
+ * pm_g1_bases_from_dev, ideally with pm_g1_bases_precompute).  transcript_label NULL = "plonk". */
+int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, const void* d_witness,
+                   const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out);
+
 /* Keccak-f[1600] on a 200-byte state (host; the permutation under the Merlin / STROBE-128 transcript
  * the prover derives its challenges from -- merlin is a dependency of dusk-plonk, ref:Cargo.toml:19). */
 void pm_keccak_f1600(uint8_t state[200]);

@@ -28,6 +28,12 @@ class QuotientArgs(C.Structure):
                 ("k", (C.c_uint64 * 4) * 3), ("zh_inv", (C.c_uint64 * 4) * 4)]
 
 
+class PlonkProof(C.Structure):
+    """``pm_plonk_proof``"""
+    _fields_ = [("commitments", (C.c_uint64 * 12) * 11), ("evaluations", (C.c_uint64 * 4) * 10),
+                ("challenges", (C.c_uint64 * 4) * 6)]
+
+
 LINCOMB_MAX = 16
 
 # name -> (restype, argtypes); must list every function the header declares
@@ -74,6 +80,11 @@ SIGNATURES = {
     "pm_plonk_perm_terms_dev": (C.c_int, [C.c_void_p, C.POINTER(PermArgs), C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "pm_plonk_quotient_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientArgs), C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pm_plonk_preprocess": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(C.c_int64), C.c_size_t,
+                                      C.POINTER(C.c_void_p)]),
+    "pm_plonk_key_free": (None, [C.c_void_p, C.c_void_p]),
+    "pm_plonk_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p,
+                                 C.POINTER(PlonkProof)]),
     "pm_keccak_f1600": (None, [C.c_char_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),

@@ -358,3 +358,47 @@ def check_identity(proof: Proof, n: int, pi_eval: int = 0) -> bool:
            * (ev["c"] + beta * ev["sigma_3"] + gamma) % R_MOD * (ev["d"] + gamma) % R_MOD * ev["z_next"]
            - alpha * alpha % R_MOD * l1_z) % R_MOD
     return ev["t"] * (zn - 1) % R_MOD == rhs
+
+
+# ---------------------------------------------------------------------------------------------
+class NativeProverKey:
+    """``pm_prover_key``: the same key and per-proof workspace built and owned by the library
+    (``pm_plonk_preprocess``), for ``prove_native``."""
+
+    def __init__(self, circuit: Circuit, ctx: Context):
+        self.ctx, self.n = ctx, circuit.n
+        sels = [np.ascontiguousarray(getattr(circuit, s), dtype=np.uint64).reshape(-1, 4) for s in SELECTORS]
+        ptrs = (_lib.u64p * 6)(*[a.ctypes.data_as(_lib.u64p) for a in sels])
+        idx = np.ascontiguousarray(circuit.sigma_index, dtype=np.int64).reshape(-1)
+        h = C.c_void_p()
+        ctx._check(ctx._lib.pm_plonk_preprocess(ctx._h, ptrs, idx.ctypes.data_as(C.POINTER(C.c_int64)), self.n, C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            self.ctx._lib.pm_plonk_key_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def prove_native(pk: NativeProverKey, ck: CommitKey, witness: DeviceVector, public_inputs: DeviceVector | None = None,
+                 label: bytes = b"plonk") -> Proof:
+    """The five rounds sequenced inside the library (``pm_plonk_prove``): one C-ABI call per proof, what a
+    Rust prover binds.  Same transcript, same proof as :func:`prove`."""
+    ctx = pk.ctx
+    raw = _lib.PlonkProof()
+    ctx._check(ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, witness._p,
+                                       public_inputs._p if public_inputs is not None else None, label, C.byref(raw)))
+    proof = Proof()
+    for i, name in enumerate(Proof.COMMITMENTS):
+        proof.commitments[name] = np.array(raw.commitments[i], dtype=np.uint64)
+    for i, name in enumerate(Proof.EVALUATIONS):
+        proof.evaluations[name] = np.array(raw.evaluations[i], dtype=np.uint64)
+    for i, name in enumerate(("beta", "gamma", "alpha", "z", "v", "u")):
+        proof.challenges[name] = fr_from_limbs(np.array(raw.challenges[i], dtype=np.uint64))
+    return proof

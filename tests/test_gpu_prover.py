@@ -384,3 +384,43 @@ def test_round_kernels_empty_and_bad_arguments(ctx, oracle):
     out = C.c_void_p()
     assert lib.pm_g1_bases_from_dev(h, None, 0, C.byref(out)) == 0 and lib.pm_g1_bases_len(out) == 0
     lib.pm_g1_bases_free(h, out)
+
+
+@pytest.mark.parametrize("n,with_pi", [(4, True), (64, True), (1024, False), (1 << 14, True)])
+def test_native_prover_equals_the_python_sequence(ctx, oracle, n, with_pi):
+    """pm_plonk_prove (rounds and Merlin transcript in C++ inside the library) must return the very
+    proof prover.prove() returns -- commitments, evaluations and challenges."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    circuit, wit, pub = pa.synthetic.chain_circuit(n, 500 + n)
+    srs = oracle.g1_bases_arith(ints_to_limbs([0xBEEF], 4)[0], ints_to_limbs([0x10000001], 4)[0], n, 8)
+    ck = pa.CommitKey(srs, ctx, precompute=(n >= 64))
+    d_wit = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
+    d_pub = pa.DeviceVector.from_host(ctx, pub) if with_pi else None
+    ref = PR.prove(PR.preprocess(circuit, ctx), ck, d_wit, d_pub)
+    npk = PR.NativeProverKey(circuit, ctx)
+    got = PR.prove_native(npk, ck, d_wit, d_pub)
+    assert got.challenges == ref.challenges
+    assert got.to_bytes() == ref.to_bytes()
+    again = PR.prove_native(npk, ck, d_wit, d_pub)                  # workspace reuse
+    assert again.to_bytes() == ref.to_bytes()
+    other = PR.prove_native(npk, ck, d_wit, d_pub, label=b"another protocol")
+    assert other.challenges["beta"] != ref.challenges["beta"]
+    npk.free()
+
+
+def test_native_prover_rejects_bad_input(ctx, oracle):
+    import ctypes as C
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    circuit, wit, pub = pa.synthetic.chain_circuit(16, 3)
+    bad = PR.Circuit(**{**circuit.__dict__, "sigma_index": circuit.sigma_index.copy()})
+    bad.sigma_index[0, 0] = bad.sigma_index[0, 1]
+    with pytest.raises(pa.Error):
+        PR.NativeProverKey(bad, ctx)
+    npk = PR.NativeProverKey(circuit, ctx)
+    short = pa.CommitKey(oracle.g1_bases_arith(ints_to_limbs([1], 4)[0], ints_to_limbs([1], 4)[0], 8, 1), ctx)
+    with pytest.raises(pa.Error) as e:
+        PR.prove_native(npk, short, pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)))
+    assert e.value.code == -6
+    npk.free()
