@@ -91,7 +91,34 @@ int main() {
     DevicePolynomial px(ctx, std::vector<Fr>{da.evaluate(x)}), pz(ctx, std::vector<Fr>{da.evaluate(z)});
     DevicePolynomial qx(ctx, std::vector<Fr>{q.evaluate(x)}), dx(ctx, std::vector<Fr>{x}), dz(ctx, std::vector<Fr>{z});
     REQUIRE(px.sub(pz).to_host() == qx.mul(dx.sub(dz)).to_host());
-    std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial over %s)\n", pm_version());
+
+    // ---- ProverKey / prove: a 64-gate circuit  a - c = 0  (q_l = 1, q_o = -1), no copy constraints ----
+    const size_t gn = 64;
+    const Fr zero{0, 0, 0, 0}, one = EvaluationDomain::one();
+    const Fr minus_one = DevicePolynomial(ctx, std::vector<Fr>{zero}).sub(DevicePolynomial(ctx, std::vector<Fr>{one})).to_host()[0];
+    std::array<std::vector<Fr>, 6> sel;
+    for (auto& v : sel) v.assign(gn, zero);
+    sel[1].assign(gn, one);                                 // q_l
+    sel[3].assign(gn, minus_one);                           // q_o
+    std::vector<int64_t> sigma(4 * gn);
+    for (size_t p2 = 0; p2 < 4 * gn; ++p2) sigma[p2] = (int64_t)p2;
+    std::vector<Fr> wit(4 * gn);
+    for (size_t i = 0; i < gn; ++i) {
+      wit[i] = wit[2 * gn + i] = random_fr();               // a = c
+      wit[gn + i] = random_fr();
+      wit[3 * gn + i] = random_fr();
+    }
+    ProverKey pk(ctx, sel, sigma);
+    CommitKey ck64(ctx, std::vector<G1Affine>(pts.begin(), pts.begin() + gn));
+    DevicePolynomial dwit(ctx, wit);
+    Proof proof = pk.prove(ck64, dwit);
+    Proof proof2 = pk.prove(ck64, dwit);
+    REQUIRE(proof.commitments == proof2.commitments && proof.evaluations == proof2.evaluations);
+    EvaluationDomain dom64(ctx, gn);
+    REQUIRE(proof.commitments[0] == ck64.commit(dom64.ifft(std::vector<Fr>(wit.begin(), wit.begin() + gn))));   // [a]
+    REQUIRE(proof.commitments[0] == proof.commitments[2]);  // a = c as polynomials
+    REQUIRE(pk.prove(ck64, dwit, nullptr, "other").challenges[0] != proof.challenges[0]);
+    std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial, ProverKey over %s)\n", pm_version());
     return 0;
   } catch (const Error& e) {
     std::fprintf(stderr, "plonk_mi355x::Error %d: %s\n", e.code, e.what());

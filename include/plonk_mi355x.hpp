@@ -17,6 +17,7 @@
 #ifndef PLONK_MI355X_HPP
 #define PLONK_MI355X_HPP
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <stdexcept>
@@ -221,6 +222,52 @@ class DevicePolynomial {
   Context* ctx_;
   void* p_ = nullptr;
   size_t n_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// dusk_plonk::proof_system::{ProverKey, Prover::prove_with_preprocessed, Proof} for the arithmetic gate
+// and the 4-wire permutation: one library call per proof (pm_plonk_prove), everything resident in HBM.
+struct Proof {
+  std::array<G1Affine, 11> commitments;  // a b c d z t_1 t_2 t_3 t_4 w_z w_zw
+  std::array<Fr, 10> evaluations;        // a b c d sigma_1 sigma_2 sigma_3 z_next t r
+  std::array<Fr, 6> challenges;          // beta gamma alpha z v u
+};
+
+class ProverKey {
+ public:
+  // selectors: q_m q_l q_r q_o q_4 q_c, n evaluations on H each; sigma_index[j n + i] = successor position
+  ProverKey(Context& ctx, const std::array<std::vector<Fr>, 6>& selectors, const std::vector<int64_t>& sigma_index)
+      : ctx_(&ctx), n_(selectors[0].size()) {
+    const uint64_t* ptrs[6];
+    for (int s = 0; s < 6; ++s) {
+      if (selectors[s].size() != n_ || n_ == 0) throw Error(PM_ERR_LENGTH, "selectors differ in length");
+      ptrs[s] = selectors[s][0].data();
+    }
+    if (sigma_index.size() != 4 * n_) throw Error(PM_ERR_LENGTH, "sigma_index must have 4n entries");
+    ctx.check(pm_plonk_preprocess(ctx.get(), ptrs, sigma_index.data(), n_, &key_));
+  }
+  ~ProverKey() { if (key_) pm_plonk_key_free(ctx_->get(), key_); }
+  ProverKey(const ProverKey&) = delete;
+  ProverKey& operator=(const ProverKey&) = delete;
+  size_t n() const { return n_; }
+  // witness: [a | b | c | d] on the device (4n); public_inputs: n evaluations of PI on H or nullptr
+  Proof prove(const CommitKey& ck, const DevicePolynomial& witness, const DevicePolynomial* public_inputs = nullptr,
+              const char* transcript_label = nullptr) const {
+    if (witness.len() != 4 * n_) throw Error(PM_ERR_LENGTH, "the witness must hold 4n wire values");
+    pm_plonk_proof raw;
+    ctx_->check(pm_plonk_prove(ctx_->get(), key_, ck.bases(), witness.data(), public_inputs ? public_inputs->data() : nullptr,
+                               transcript_label, &raw));
+    Proof p;
+    for (int i = 0; i < 11; ++i) std::copy(raw.commitments[i], raw.commitments[i] + 12, p.commitments[i].begin());
+    for (int i = 0; i < 10; ++i) std::copy(raw.evaluations[i], raw.evaluations[i] + 4, p.evaluations[i].begin());
+    for (int i = 0; i < 6; ++i) std::copy(raw.challenges[i], raw.challenges[i] + 4, p.challenges[i].begin());
+    return p;
+  }
+
+ private:
+  Context* ctx_;
+  size_t n_;
+  pm_prover_key* key_ = nullptr;
 };
 
 }  // namespace plonk_mi355x
