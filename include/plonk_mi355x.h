@@ -18,6 +18,12 @@
  *   pm_g1_msm                    <- dusk_bls12_381::multiscalar_mul::msm_variable_base
  *                                   [ark-ec: VariableBaseMSM::multi_scalar_mul]        a9
  *   pm_g1_fold / pm_g1_to_affine <- G1Projective `+` / G1Affine::from (multi-GPU fold)  a8
+ *   pm_fr_*_dev, pm_plonk_*_dev  <- fft::{Polynomial, Evaluations}, proof_system::{permutation,
+ *                                   quotient_poly, linearisation_poly} pointwise work   8f N1/N2
+ *   pm_plonk_preprocess / _prove <- proof_system::{ProverKey, Prover::prove_with_preprocessed}:
+ *                                   the whole five-round prover behind one call        8f N1-N3
+ *   pm_g1_fixed_base_mul_dev     <- PublicParameters::setup (powers of tau)             8f N4
+ * (include/plonk_mi355x.hpp is the C++ mirror of the same interfaces.)
  *
  * Data layouts are the Rust types' memory, so slices can be passed without marshalling:
  *   Fr  (BlsScalar / ark Fr)  : 4 x uint64_t little-endian limbs, Montgomery form R = 2^256,
@@ -34,7 +40,7 @@
  * Errors: every call returns PM_OK (0) or a negative pm_status; nothing unwinds across the
  * ABI.  pm_last_error(ctx) gives a human-readable string for the last failure on that ctx.
  * Threading: calls on one ctx are serialised by an internal mutex; use one ctx per thread
- * for concurrency.  One ctx drives one GPU (one process per GPU under torch.distributed).
+ * for concurrency (a pm_prover_key carries its proof workspace: one proof at a time per key).  One ctx drives one GPU (one process per GPU under torch.distributed).
  * There is no CPU fallback: without a usable gfx950 device pm_init fails with
  * PM_ERR_NO_DEVICE.
  */
