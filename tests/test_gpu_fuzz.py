@@ -175,7 +175,7 @@ def test_prove_many_seeds(ctx, oracle):
     import plonk_prototype_amd as pa
     import plonk_prototype_amd.prover as PR
     srs = oracle.g1_bases_arith(ints_to_limbs([11], 4)[0], ints_to_limbs([0x10001], 4)[0], 2048, 8)
-    for seed, n in ((1, 8), (2, 32), (3, 128), (4, 512), (5, 2048)):
+    for seed, n in [(1 + SEED, 8), (2 + SEED, 32), (3 + SEED, 128), (4 + SEED, 512), (5 + SEED, 2048)] * min(SCALE, 4):
         circuit, wit, pub = pa.synthetic.chain_circuit(n, seed)
         pk = PR.preprocess(circuit, ctx)
         ck = pa.CommitKey(srs[:n], ctx, precompute=(seed % 2 == 0))
@@ -189,3 +189,8 @@ def test_prove_many_seeds(ctx, oracle):
         # a second proof from the same key reuses the workspace and must be identical
         again = PR.prove(pk, ck, wit, pub)
         assert again.to_bytes() == blob
+        # and the native sequence (pm_plonk_prove) returns the same bytes
+        npk = PR.NativeProverKey(circuit, ctx)
+        d_w, d_p = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)), pa.DeviceVector.from_host(ctx, pub)
+        assert PR.prove_native(npk, ck, d_w, d_p).to_bytes() == blob
+        npk.free()
