@@ -536,7 +536,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
 
   // workspace layout
   size_t sort_tmp = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const u32*)nullptr, (u32*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const u32*)nullptr, (u32*)nullptr,
                                      (const u32*)nullptr, (u32*)nullptr, (int)m, 0, (int)g.key_bits, st);
   size_t off = 0;
   auto take = [&](size_t bytes) {
