@@ -269,6 +269,15 @@ void pm_plonk_key_free(pm_ctx* ctx, pm_prover_key* key);
  * pm_g1_bases_from_dev, ideally with pm_g1_bases_precompute).  transcript_label NULL = "plonk". */
 int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, const void* d_witness,
                    const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out);
+/* The same proof with the SRS split over the GPUs of a node (BASELINE.json configs[4]): every rank calls
+ * this with the same witness and its own slice of the commit key -- bases for coefficients
+ * [first_coefficient, first_coefficient + pm_g1_bases_len(slice)) -- and `exchange` turns this rank's k
+ * partial points (k x 18 limbs, in place) into the sums over all ranks: an all-gather of k x 144 bytes
+ * (ncclAllGather over xGMI) followed by pm_g1_fold per point.  Returns non-zero to abort. */
+typedef int (*pm_exchange_fn)(void* user, uint64_t* xyz, uint32_t k);
+int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key_slice, size_t first_coefficient,
+                           const void* d_witness, const void* d_public_inputs, const char* transcript_label,
+                           pm_exchange_fn exchange, void* user, pm_plonk_proof* out);
 
 /* Keccak-f[1600] on a 200-byte state (host; the permutation under the Merlin / STROBE-128 transcript
  * the prover derives its challenges from -- merlin is a dependency of dusk-plonk, ref:Cargo.toml:19). */

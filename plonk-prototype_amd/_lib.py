@@ -34,6 +34,7 @@ class PlonkProof(C.Structure):
                 ("challenges", (C.c_uint64 * 4) * 6)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint32)
 LINCOMB_MAX = 16
 
 # name -> (restype, argtypes); must list every function the header declares
@@ -85,6 +86,8 @@ SIGNATURES = {
     "pm_plonk_key_free": (None, [C.c_void_p, C.c_void_p]),
     "pm_plonk_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p,
                                  C.POINTER(PlonkProof)]),
+    "pm_plonk_prove_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(PlonkProof)]),
     "pm_keccak_f1600": (None, [C.c_char_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),

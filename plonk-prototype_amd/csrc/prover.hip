@@ -10,6 +10,7 @@
 // vector work is done by the library's own entry points, called like any client would call them.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -265,10 +266,27 @@ extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[
   return PM_OK;
 }
 
-static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const void* d, size_t n, size_t stride, uint32_t batch,
-                        u64 (*out_xy)[12]) {
+// Commitments to `batch` coefficient vectors of n elements.  With the SRS split over ranks (shard.fn set)
+// this rank's bases cover coefficients [shard.lo, shard.lo + len(ck)): it computes the partial sums of its
+// slice and the exchange callback returns the sums over all ranks (all-gather + group-law fold).
+struct Shard {
+  size_t lo = 0;
+  pm_exchange_fn fn = nullptr;
+  void* user = nullptr;
+};
+static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const void* d, size_t n, size_t stride,
+                        uint32_t batch, u64 (*out_xy)[12]) {
   u64 xyz[4 * 18];
-  PK_TRY(pm_g1_msm_batch_dev(ctx, ck, 0, n, d, stride, batch, PM_SCALAR_MONTGOMERY, xyz, nullptr));
+  const size_t have = pm_g1_bases_len(ck);
+  size_t cnt = n;
+  if (sh.fn) cnt = sh.lo < n ? std::min(have, n - sh.lo) : 0;
+  if (cnt > 0) {
+    PK_TRY(pm_g1_msm_batch_dev(ctx, ck, 0, cnt, at((void*)d, sh.lo), stride, batch, PM_SCALAR_MONTGOMERY, xyz, nullptr));
+  } else {
+    memset(xyz, 0, sizeof xyz);
+    for (uint32_t b = 0; b < batch; ++b) memcpy(xyz + 18 * b + 6, pm::host::FP().one, 48);   // (0, 1, 0)
+  }
+  if (sh.fn && sh.fn(sh.user, xyz, batch) != 0) return PM_ERR_BAD_ARG;
   for (uint32_t b = 0; b < batch; ++b) {
     int ident = 0;
     PK_TRY(pm_g1_to_affine(xyz + 18 * b, out_xy[b], &ident));
@@ -276,19 +294,38 @@ static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const void* d, size_t n
   return PM_OK;
 }
 
+static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
+                      const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out);
+
+extern "C" int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck_slice, size_t first_coefficient,
+                                      const void* d_witness, const void* d_public_inputs, const char* transcript_label,
+                                      pm_exchange_fn exchange, void* user, pm_plonk_proof* out) {
+  if (!exchange) return PM_ERR_BAD_ARG;
+  Shard sh;
+  sh.lo = first_coefficient;
+  sh.fn = exchange;
+  sh.user = user;
+  return prove_impl(ctx, pk, ck_slice, sh, d_witness, d_public_inputs, transcript_label, out);
+}
+
 extern "C" int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const void* d_witness,
                               const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out) {
+  return prove_impl(ctx, pk, ck, Shard(), d_witness, d_public_inputs, transcript_label, out);
+}
+
+static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
+                      const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out) {
   if (!ctx || !pk || !ck || !d_witness || !out) return PM_ERR_BAD_ARG;
   const size_t n = pk->n;
   const uint32_t lg = pk->log_n;
-  if (pm_g1_bases_len(ck) < n) return PM_ERR_LENGTH;
+  if (!shard.fn && pm_g1_bases_len(ck) < n) return PM_ERR_LENGTH;
   Transcript ts(transcript_label ? transcript_label : "plonk");
   ts.append("dom-sep", (const uint8_t*)"circuit_size", 12);
   ts.append_u64("n", n);
   const HFr one = fone();
   // ---- round 1 --------------------------------------------------------------------------------
   PK_TRY(pm_fr_ntt_dev(ctx, d_witness, n, n, pk->coeffs, n, lg, 4, PM_NTT_INVERSE, nullptr));
-  PK_TRY(commit_batch(ctx, ck, pk->coeffs, n, n, 4, &out->commitments[0]));
+  PK_TRY(commit_batch(ctx, ck, shard, pk->coeffs, n, n, 4, &out->commitments[0]));
   const char* wl[4] = {"w_a", "w_b", "w_c", "w_d"};
   for (int j = 0; j < 4; ++j) ts.append_commitment(wl[j], out->commitments[j]);
   // ---- round 2 --------------------------------------------------------------------------------
@@ -309,7 +346,7 @@ extern "C" int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck
   PK_TRY(pm_fr_prefix_product_dev(ctx, pk->num, n, pk->den, nullptr));
   void* z_coeffs = at(pk->coeffs, 4 * n);
   PK_TRY(pm_fr_ntt_dev(ctx, pk->den, n, n, z_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
-  PK_TRY(commit_batch(ctx, ck, z_coeffs, n, n, 1, &out->commitments[4]));
+  PK_TRY(commit_batch(ctx, ck, shard, z_coeffs, n, n, 1, &out->commitments[4]));
   ts.append_commitment("z", out->commitments[4]);
   // ---- round 3 --------------------------------------------------------------------------------
   const HFr alpha = ts.challenge_scalar("alpha");
@@ -341,7 +378,7 @@ extern "C" int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck
   for (int j = 0; j < 4; ++j) put(qa.zh_inv[j], pk->zh_inv[j]);
   PK_TRY(pm_plonk_quotient_dev(ctx, &qa, n, pk->t, nullptr));
   PK_TRY(pm_fr_ntt_dev(ctx, pk->t, 4 * n, 4 * n, pk->t, 4 * n, lg + 2, 1, PM_NTT_INVERSE | PM_NTT_COSET, nullptr));
-  PK_TRY(commit_batch(ctx, ck, pk->t, n, n, 4, &out->commitments[5]));
+  PK_TRY(commit_batch(ctx, ck, shard, pk->t, n, n, 4, &out->commitments[5]));
   const char* tl[4] = {"t_1", "t_2", "t_3", "t_4"};
   for (int i = 0; i < 4; ++i) ts.append_commitment(tl[i], out->commitments[5 + i]);
   // ---- round 4 --------------------------------------------------------------------------------
@@ -401,7 +438,7 @@ extern "C" int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck
   PK_TRY(pm_fr_lincomb_dev(ctx, 12, agg_v, &agg_c[0][0], n, pk->agg, nullptr));
   PK_TRY(pm_fr_poly_ruffini_dev(ctx, pk->agg, n, zc.l, pk->wit, nullptr));
   PK_TRY(pm_fr_poly_ruffini_dev(ctx, z_coeffs, n, zw.l, at(pk->wit, n), nullptr));
-  PK_TRY(commit_batch(ctx, ck, pk->wit, n - 1, n, 2, &out->commitments[9]));
+  PK_TRY(commit_batch(ctx, ck, shard, pk->wit, n - 1, n, 2, &out->commitments[9]));
   ts.append_commitment("w_z", out->commitments[9]);
   ts.append_commitment("w_zw", out->commitments[10]);
   const HFr u = ts.challenge_scalar("u");

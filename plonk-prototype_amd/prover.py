@@ -392,8 +392,22 @@ def prove_native(pk: NativeProverKey, ck: CommitKey, witness: DeviceVector, publ
     Rust prover binds.  Same transcript, same proof as :func:`prove`."""
     ctx = pk.ctx
     raw = _lib.PlonkProof()
-    ctx._check(ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, witness._p,
-                                       public_inputs._p if public_inputs is not None else None, label, C.byref(raw)))
+    d_pi = public_inputs._p if public_inputs is not None else None
+    if hasattr(ck, "lo"):       # dist.ShardedCommitKey: this rank's slice of the SRS, partial sums exchanged
+        from .dist import allgather_fold_many
+
+        def exchange(_user, xyz, k):
+            try:
+                buf = np.ctypeslib.as_array(xyz, shape=(k, 18))
+                buf[:] = allgather_fold_many(buf.copy(), ck.device)
+                return 0
+            except Exception:            # never unwind through the C frames
+                return 1
+        cb = _lib.EXCHANGE_FN(exchange)
+        ctx._check(ctx._lib.pm_plonk_prove_sharded(ctx._h, pk._h, ck._bases._h, ck.lo, witness._p, d_pi, label,
+                                                   C.cast(cb, C.c_void_p), None, C.byref(raw)))
+    else:
+        ctx._check(ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, witness._p, d_pi, label, C.byref(raw)))
     proof = Proof()
     for i, name in enumerate(Proof.COMMITMENTS):
         proof.commitments[name] = np.array(raw.commitments[i], dtype=np.uint64)

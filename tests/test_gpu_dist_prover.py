@@ -50,6 +50,11 @@ def _worker(rank, world, port, q):
         ck = ShardedCommitKey(srs[lo:hi], lo, N, ctx, precompute=(rank == 0))   # mixed table / no table
         pk = pa.preprocess(circuit, ctx)
         proof = pa.prove(pk, ck, wit, pi)
+        # the native sequence with the exchange callback must agree with the Python one on every rank
+        npk = pa.NativeProverKey(circuit, ctx)
+        nat = pa.prove_native(npk, ck, pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)), pa.DeviceVector.from_host(ctx, pi))
+        assert nat.to_bytes() == proof.to_bytes()
+        npk.free()
         q.put((rank, _proof_blob(proof).tolist()))
         ctx.close()
     finally:
