@@ -12,9 +12,10 @@ pts = o.g1_bases_arith(ints_to_limbs([0x1234567], 4)[0], ints_to_limbs([0xabcdef
 sc = o.fr_sample(0x5343414C, n)
 d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
 ref = None
-for c in (17, 18, 19, 20, 21):
+cs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (17, 18, 19, 20, 21)
+for c in cs:
     bases = pa.host.Bases(ctx, pts).precompute(c)
-    for lb in (4, 8, 16, 32):
+    for lb in ([int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (4, 8, 16, 32)):
         ctx.set_option("msm_lb", lb)
         r = bases.msm_dev(d_sc.data_ptr(), n)
         if ref is None: ref = r
