@@ -17,13 +17,28 @@ int set_err(pm_ctx* ctx, int code, const std::string& msg) {
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   if (b.bytes >= bytes && b.ptr) return PM_OK;
   if (b.ptr) {
-    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PM_HIP(ctx, hipDeviceSynchronize());   // the old buffer may still be in use on any caller stream
     PM_HIP(ctx, hipFree(b.ptr));
     b.ptr = nullptr;
     b.bytes = 0;
   }
   PM_HIP(ctx, hipMalloc(&b.ptr, bytes));
   b.bytes = bytes;
+  return PM_OK;
+}
+
+int order_on(pm_ctx* ctx, StreamOrder& o, hipStream_t st) {
+  if (o.used && o.last != st) {
+    if (!o.ev) PM_HIP(ctx, hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
+    if (hipEventRecord(o.ev, o.last) == hipSuccess) {
+      PM_HIP(ctx, hipStreamWaitEvent(st, o.ev, 0));
+    } else {   // the caller destroyed its previous stream: everything on it has been submitted, wait for the device
+      (void)hipGetLastError();
+      PM_HIP(ctx, hipDeviceSynchronize());
+    }
+  }
+  o.last = st;
+  o.used = true;
   return PM_OK;
 }
 
@@ -107,7 +122,7 @@ extern "C" int pm_init(int device_id, pm_ctx** out) {
 extern "C" void pm_shutdown(pm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  hipDeviceSynchronize();
   for (int d = 0; d < 2; ++d) {
     for (auto& kv : ctx->step_tw[d]) hipFree(kv.second);
     for (auto& kv : ctx->step4_tw[d]) hipFree(kv.second);
@@ -123,6 +138,8 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
                           &ctx->msm_scalars, &ctx->poly_ws, &ctx->poly_tab})
     if (b->ptr) hipFree(b->ptr);
   if (ctx->msm_host_pinned) hipHostFree(ctx->msm_host_pinned);
+  for (StreamOrder* o : {&ctx->ord_ntt, &ctx->ord_msm, &ctx->ord_poly})
+    if (o->ev) (void)hipEventDestroy(o->ev);
   prof_collect(ctx);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->copy_in) hipStreamDestroy(ctx->copy_in);
@@ -235,7 +252,15 @@ extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const ui
   if (n == 0) return PM_OK;
   PM_HIP(ctx, hipSetDevice(ctx->device));
   const size_t esz = op < 3 ? 32 : 48;
-  void *da, *db, *dc;
+  void *da = nullptr, *db = nullptr, *dc = nullptr;
+  struct Free3 {   // the temporaries go away on every path, error returns included
+    void **a, **b, **c;
+    ~Free3() {
+      if (*a) (void)hipFree(*a);
+      if (*b) (void)hipFree(*b);
+      if (*c) (void)hipFree(*c);
+    }
+  } free3{&da, &db, &dc};
   PM_HIP(ctx, hipMalloc(&da, n * esz));
   PM_HIP(ctx, hipMalloc(&db, n * esz));
   PM_HIP(ctx, hipMalloc(&dc, n * esz));
@@ -255,8 +280,5 @@ extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const ui
   PM_HIP(ctx, hipGetLastError());
   PM_HIP(ctx, hipMemcpyAsync(out, dc, n * esz, hipMemcpyDeviceToHost, ctx->stream));
   PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(da);
-  hipFree(db);
-  hipFree(dc);
   return PM_OK;
 }

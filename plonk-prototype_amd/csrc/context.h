@@ -16,6 +16,18 @@ struct DeviceBuffer {
   size_t bytes = 0;
 };
 
+// A group of shared resources (scratch buffers, lazily built tables) that calls on different HIP
+// streams would otherwise race on.  Every call that touches the group goes through order_on():
+// when the stream differs from the one that used the group last, the new stream first waits for
+// an event recorded on the old one, so a context behaves like one in-order queue per group even
+// when its *_dev entry points are driven from several streams.  Groups are independent: an NTT on
+// one stream and an MSM on another still overlap.
+struct StreamOrder {
+  hipStream_t last = nullptr;
+  bool used = false;
+  hipEvent_t ev = nullptr;
+};
+
 struct NttDomainTables {  // per (log_n, direction)
   void* tw_hi = nullptr;
   void* tw_lo = nullptr;
@@ -40,6 +52,8 @@ struct pm_ctx {
   std::map<unsigned, pm::NttDomainTables> domain[2];    // [dir][log_n]
   pm::DeviceBuffer ntt_tmp[2];
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
+  pm::StreamOrder ord_ntt, ord_msm, ord_poly;           // cross-stream ordering of the shared scratch + tables
+  std::map<const void*, bool> big_lds_set;              // kernels whose dynamic-LDS limit was already raised
   // MSM workspaces
   pm::DeviceBuffer msm_ws;
   pm::DeviceBuffer msm_scalars;
@@ -94,6 +108,7 @@ struct ProfScope {
 };
 int prof_collect(pm_ctx* ctx);
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
+int order_on(pm_ctx* ctx, StreamOrder& o, hipStream_t st);
 
 #define PM_HIP(ctx, call)                                                                   \
   do {                                                                                      \

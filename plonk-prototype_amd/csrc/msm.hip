@@ -206,9 +206,15 @@ struct AccArgs {
   u32 trash;                // level 1: first key that is not a bucket
   u32 final_level;          // 1: every run goes to its bucket
   u32x4* buckets;           // XYZZ, indexed by key
-  u32* part_keys;           // 2 per thread: [2t] head run, [2t+1] tail run
-  u32x4* part_pts;
+  u32* part_keys;           // partial list written by this level: level 1 two per WAVE ([2w] the run that
+  u32x4* part_pts;          // enters the wave from the left, [2w+1] the run that leaves it to the right),
+                            // deeper levels two per thread; keys carry PART_OL / PART_OR
+  u32x4* head_pts;          // level 1 scratch, one slot per thread: a first run that continues from the left
 };
+// A partial-list key = bucket key | PART_OL (the run continues from an earlier entry) | PART_OR (it
+// continues in a later entry).  Entries of one run are adjacent in the list (holes aside), so a
+// run is complete exactly when its first entry has no PART_OL and its last no PART_OR.
+static constexpr u32 PART_OL = 0x80000000u, PART_OR = 0x40000000u, PART_KEY = 0x3fffffffu;
 
 PM_DEV Xyzz xyzz_shfl_up1(const Xyzz& v) {
   Xyzz r;
@@ -220,6 +226,18 @@ PM_DEV Xyzz xyzz_shfl_up1(const Xyzz& v) {
     r.zzz.l[i] = __shfl_up(v.zzz.l[i], 1);
   }
   r.inf = __shfl_up((int)v.inf, 1) != 0;
+  return r;
+}
+PM_DEV Xyzz xyzz_shfl_up(const Xyzz& v, int d) {
+  Xyzz r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    r.x.l[i] = __shfl_up(v.x.l[i], d);
+    r.y.l[i] = __shfl_up(v.y.l[i], d);
+    r.zz.l[i] = __shfl_up(v.zz.l[i], d);
+    r.zzz.l[i] = __shfl_up(v.zzz.l[i], d);
+  }
+  r.inf = __shfl_up((int)v.inf, d) != 0;
   return r;
 }
 PM_DEV Xyzz xyzz_shfl_down(const Xyzz& v, int d) {
@@ -235,33 +253,92 @@ PM_DEV Xyzz xyzz_shfl_down(const Xyzz& v, int d) {
   return r;
 }
 
+// Joins the open pieces the lanes of one wave hold (all 64 lanes call it).  Per lane:
+//   open      the lane passes something to the right: its own piece `acc` with key `cur` (a "tail",
+//             which starts a segment), or -- `through` -- whatever arrives from the left plus `acc`
+//   have_head the lane holds the END of a run that arrives from the left: key head_key, value in
+//             memory at head_src[head_idx] (kept out of the register file until it is needed)
+// A segmented scan over the lanes sums every segment; the lane with the head adds it and stores
+// the bucket.  What enters the wave from the left edge goes to partial slot 2w (PART_OL), what
+// leaves it to the right to slot 2w+1 (PART_OR, plus PART_OL when it also entered from the left).
+// At the final level (one wave holds the whole list) nothing can cross an edge; if a malformed
+// list claims otherwise the piece is stored to its bucket.
+PM_DEV void wave_join(const AccArgs& a, size_t wave, bool wave_live, u32 lane, bool open, bool through, u32 cur,
+                      Xyzz& acc, bool have_head, u32 head_key, const u32x4* head_src, size_t head_idx) {
+  if (!open) acc = xyzz_identity();
+  int flag = (open && through) ? 0 : 1;  // 1: a segment starts here (a tail, or nothing to pass on)
+  for (int d = 1; d < 64; d <<= 1) {
+    if (__ballot(flag == 0) == 0) break;  // wave-uniform: every segment has found its start
+    const Xyzz up = xyzz_shfl_up(acc, d);
+    const int fup = __shfl_up(flag, d);
+    const u32 kup = __shfl_up(cur, d);
+    if ((int)lane >= d && !flag) {
+      acc = xyzz_add(up, acc);
+      if (cur == KEY_INVALID) cur = kup;   // a hole takes the key of the chain it passes on
+      flag = fup;
+    }
+  }
+  // acc (open lanes): sum of the run from its start inside the wave -- or from the wave's left
+  // edge when flag is still 0 -- up to this lane
+  const Xyzz from_up = xyzz_shfl_up(acc, 1);
+  const bool up_open = (__shfl_up((int)open, 1) != 0) && lane != 0;
+  const bool up_started = (__shfl_up(flag, 1) != 0) && lane != 0;
+  const bool wave_head = have_head && !(up_open && up_started);  // the run entered the wave from the left
+  const bool wave_tail = open && (lane == 63u) && cur != KEY_INVALID;
+  const bool any_head = __ballot(wave_head) != 0;
+  if (wave_tail) {  // leaves the wave to the right
+    if (a.final_level) {
+      st_xyzz(a.buckets, cur, acc);
+    } else {
+      a.part_keys[2 * wave + 1] = cur | PART_OR | (flag ? 0u : PART_OL);
+      st_xyzz(a.part_pts, 2 * wave + 1, acc);
+    }
+  } else if (lane == 63u && wave_live && !a.final_level) {
+    a.part_keys[2 * wave + 1] = KEY_INVALID;
+  }
+  if (lane == 0u && !any_head && wave_live && !a.final_level) a.part_keys[2 * wave] = KEY_INVALID;
+  // (acc is dead from here on: the merge below needs the registers)
+  if (have_head) {
+    Xyzz h = ld_xyzz(head_src, head_idx);
+    if (up_open) h = xyzz_add(from_up, h);
+    if (wave_head && !a.final_level) {
+      a.part_keys[2 * wave] = head_key | PART_OL;
+      st_xyzz(a.part_pts, 2 * wave, h);
+    } else {
+      st_xyzz(a.buckets, head_key, h);
+    }
+  }
+}
+
 // Level 1: sorted (key, point index) pairs, affine bases, one thread per chunk of `chunk`
 // entries.  A run is classified exactly by looking one key past either end of the chunk:
 //   neither continues    -> complete, stored to its bucket
-//   continues both ways  -> pass-through partial (slot 2t+1)
-//   tail that continues after / head that continues from before: the usual case for uniform
-//   digits is a run split over exactly two neighbouring chunks, i.e. neighbouring LANES, so
-//   lane i hands its open tail to lane i+1 through the register file (one shuffle of the
-//   point) and lane i+1 completes the run with one addition.  Only runs that cross a wave
-//   boundary or span three or more chunks reach the partial list.
+//   first run that continues from the left and ends inside the chunk -> "head", parked in head_pts[t]
+//   last run that continues to the right -> stays in registers: "tail" if it started inside the
+//                           chunk, "through" if the whole chunk is one run open on both sides
+// The open pieces of a wave are then joined in the register file by a segmented scan over the
+// lanes: a tail starts a segment, through lanes extend it, and the lane holding the head of the
+// same run adds its parked head and stores the bucket.  For uniform digits with chunks of a few
+// run lengths a run is split over exactly two neighbouring lanes and the scan degenerates to one
+// shuffle and one addition (no through lanes: the loop below does not iterate); long runs (small
+// n, skewed or all-equal scalars) cost up to six additions per wave instead of a pass through a
+// per-thread partial list.  Only what crosses a WAVE boundary is left for the next level: two
+// partial slots per wave.
 __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (a.len + a.chunk - 1) / a.chunk;
   const bool active = t < nthreads;
   const u32 lane = threadIdx.x & 63u;
+  const size_t wave = t >> 6;
   const size_t lo = t * a.chunk, hi = lo + a.chunk < a.len ? lo + a.chunk : a.len;
   u32 prev_key = KEY_INVALID, next_key = KEY_INVALID;
   if (active) {
-    if (!a.final_level) {
-      a.part_keys[2 * t] = KEY_INVALID;
-      a.part_keys[2 * t + 1] = KEY_INVALID;
-    }
     if (lo > 0) prev_key = a.keys[lo - 1];
     if (hi < a.len) next_key = a.keys[hi];
     if (next_key >= a.trash) next_key = KEY_INVALID;
   }
   u32 cur = KEY_INVALID, head_key = KEY_INVALID;
-  bool first_run = true, have_head = false, have_tail = false;
+  bool first_run = true, have_head = false, open = false, through = false;
   Xyzz acc = xyzz_identity();
   if (active) {
     // software pipeline: the (key, value, point) of entry e+1 is requested before the ~5000
@@ -291,9 +368,8 @@ __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs
           const bool cfb = first_run && cur == prev_key;
           if (a.final_level || !cfb) {
             st_xyzz(a.buckets, cur, acc);
-          } else {  // head continuing from the previous chunk: park it in its partial slot
-            a.part_keys[2 * t] = cur;
-            st_xyzz(a.part_pts, 2 * t, acc);
+          } else {  // head continuing from the previous chunk: park it
+            st_xyzz(a.head_pts, t, acc);
             have_head = true;
             head_key = cur;
           }
@@ -322,75 +398,44 @@ __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs
       if (a.final_level || (!cfb && !ca)) {
         st_xyzz(a.buckets, cur, acc);
       } else if (cfb && !ca) {
-        a.part_keys[2 * t] = cur;
-        st_xyzz(a.part_pts, 2 * t, acc);
+        st_xyzz(a.head_pts, t, acc);
         have_head = true;
         head_key = cur;
-      } else if (!cfb && ca) {
-        have_tail = true;  // stays in registers for the neighbour exchange
       } else {
-        a.part_keys[2 * t + 1] = cur;
-        st_xyzz(a.part_pts, 2 * t + 1, acc);
+        open = true;      // stays in registers
+        through = cfb;    // ... and also continues from the left
       }
     }
   }
-  // ---- neighbour exchange (all 64 lanes take part)
-  const bool up_has_tail = (__shfl_up((int)have_tail, 1) != 0) && lane != 0;
-  const bool down_has_head = (__shfl_down((int)have_head, 1) != 0) && lane != 63;
-  const Xyzz from_up = xyzz_shfl_up1(acc);
-  if (have_tail && !down_has_head) {  // nobody takes the tail: it goes to the partial list
-    a.part_keys[2 * t + 1] = cur;
-    st_xyzz(a.part_pts, 2 * t + 1, acc);
-  }
-  // (acc is dead from here on: the merge below needs the registers)
-  if (have_head && up_has_tail) {  // complete the run split between lane-1 and this lane
-    Xyzz h = ld_xyzz(a.part_pts, 2 * t);
-    st_xyzz(a.buckets, head_key, xyzz_add(from_up, h));
-    a.part_keys[2 * t] = KEY_INVALID;
-  }
+  if (a.final_level) return;  // a single thread: nothing can be open
+  wave_join(a, wave, (wave << 6) < nthreads, lane, open, through, cur, acc, have_head, head_key, a.head_pts, t);
 }
 
-// Level >= 2: a list of (key, XYZZ) partials in key order, with holes (KEY_INVALID).
+// Level >= 2: a list of (key | PART_OL | PART_OR, XYZZ) partials in key order, with holes
+// (KEY_INVALID): ONE entry per lane (shifted by one slot, so that the slot a run leaves wave w
+// through, 2w+1, and the slot it enters wave w+1 through, 2w+2, sit in neighbouring lanes of one
+// wave), joined by the same segmented scan.  An entry with PART_OR only starts a segment, PART_OL
+// only ends one, both continues one; a hole passes the chain on.  Every level shrinks the list by
+// 32, and a run of any length costs at most six additions per level.
 __global__ void __launch_bounds__(128) msm_accumulate_ln_kernel(const AccArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t nthreads = (a.len + a.offset + a.chunk - 1) / a.chunk;
-  if (t >= nthreads) return;
-  const size_t lo = t * a.chunk > a.offset ? t * a.chunk - a.offset : 0;
-  size_t hi = (t + 1) * (size_t)a.chunk - a.offset;
-  if (hi > a.len) hi = a.len;
-  if (!a.final_level) {
-    a.part_keys[2 * t] = KEY_INVALID;
-    a.part_keys[2 * t + 1] = KEY_INVALID;
-  }
-  u32 cur = KEY_INVALID;
-  bool first_run = true;
+  const size_t nthreads = a.len + 1;
+  const u32 lane = threadIdx.x & 63u;
+  const size_t wave = t >> 6;
+  const bool active = t >= 1 && t < nthreads;
+  const size_t e = t - 1;
+  const u32 k = active ? a.keys[e] : KEY_INVALID;
+  const bool hole = (k == KEY_INVALID);
+  const u32 key = hole ? KEY_INVALID : (k & PART_KEY);
+  const bool ol = !hole && (k & PART_OL), orr = !hole && (k & PART_OR);
+  // holes inside the list pass a chain on (through, nothing of their own); lanes outside the list end it
+  const bool open = active && (hole || orr);
+  const bool through = active && (hole || (ol && orr));
+  const bool have_head = ol && !orr;
   Xyzz acc = xyzz_identity();
-  for (size_t e = lo; e < hi; ++e) {
-    const u32 k = a.keys[e];
-    if (k == KEY_INVALID) continue;  // hole
-    if (k != cur) {
-      if (cur != KEY_INVALID) {
-        if (a.final_level || !first_run) {
-          st_xyzz(a.buckets, cur, acc);
-        } else {
-          a.part_keys[2 * t] = cur;
-          st_xyzz(a.part_pts, 2 * t, acc);
-        }
-        first_run = false;
-      }
-      cur = k;
-      acc = xyzz_identity();
-    }
-    acc = xyzz_add(acc, ld_xyzz(a.pts_in, e));
-  }
-  if (cur != KEY_INVALID) {
-    if (a.final_level) {
-      st_xyzz(a.buckets, cur, acc);
-    } else {  // the last run (possibly the only one) may continue in the next chunk
-      a.part_keys[2 * t + 1] = cur;
-      st_xyzz(a.part_pts, 2 * t + 1, acc);
-    }
-  }
+  if (!hole && orr) acc = ld_xyzz(a.pts_in, e);
+  if (!hole && !ol && !orr) st_xyzz(a.buckets, key, ld_xyzz(a.pts_in, e));  // (not produced by a well-formed level)
+  wave_join(a, wave, (wave << 6) < nthreads, lane, open, through, key, acc, have_head, key, a.pts_in, e);
 }
 
 // ------------------------------------------------------------------ 4: bucket reduce
@@ -502,35 +547,45 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
   if (bases->table_c && (size_t)bases->n * ((256 + bases->table_c - 1) / bases->table_c) > 0x7fffffffu)
     return set_err(ctx, PM_ERR_BAD_ARG, "window table too large for 31-bit point indices");
+  {
+    int orc = order_on(ctx, ctx->ord_msm, st);   // msm_ws and the pinned result buffer are shared by all streams
+    if (orc) return orc;
+  }
   const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
   const size_t m = n * batch * g.nwin;  // (key, value) pairs
   const u32 nsets_all = g.nsets * batch;
   if (m > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "batch * n * windows exceeds 2^31 pairs");
-  // chunk sizes: level 1 reads L1 sorted pairs per thread; deeper levels read LN slots of the
-  // (mostly empty) partial list, shifted by LN/2 so that the two slots a wave boundary leaves
-  // behind (tail of lane 63, head of the next lane 0) fall into the same chunk
-  // Entries per thread in the big kernel (measured, profiles/r01_msm_sweep.txt): at least four times
-  // the mean run length m / #buckets -- a chunk not much longer than the runs leaves pass-through
-  // partials for the latency-bound follow-up levels (0.2 ms of them at a ratio of 4.7, 0.75 ms at
-  // 2.5) -- at least 128, and never so long that the grid drops below 2^17 threads.
+  // Entries per thread in the big kernel (measured, profiles/r01_msm_sweep.txt, r02_msm_sweep.txt): about
+  // four times the mean run length m / #buckets when the grid allows it (then a run is split over at
+  // most two neighbouring lanes and the in-wave join costs one addition), at least 128, and never so
+  // long that the grid drops below 2^17 threads; small inputs end up with chunks shorter than a run
+  // and pay up to six additions per wave in the segmented scan instead.
   const size_t avg_run = std::max<size_t>(1, m / ((size_t)g.nbuckets * nsets_all));
   const u32 L1 = ctx->opt_msm_chunk
                      ? (u32)ctx->opt_msm_chunk
                      : (u32)std::max<size_t>(16, std::min<size_t>(m >> 17, std::max<size_t>(128, 4 * avg_run)));
-  const u32 LN = 8, LN_OFF = 4;
-  std::vector<size_t> lens;  // lens[0] = m (level 1 input), lens[i] = partial list length
-  lens.push_back(m);
+  // Partial lists: every level leaves two slots per WAVE; the deeper levels take one slot per lane, so
+  // the list shrinks by 32 per level and ends in a single wave (final level).
+  struct Level {
+    size_t len;   // entries read at this level
+    u32 chunk, offset;
+  };
+  std::vector<Level> lv;
+  lv.push_back({m, L1, 0});
   {
     size_t nthr = (m + L1 - 1) / L1;
     while (nthr > 1) {
-      const size_t len = 2 * nthr;
-      lens.push_back(len);
-      nthr = (len + LN_OFF + LN - 1) / LN;
-      if (len <= 32) break;  // the next level is a single thread
+      const size_t len = 2 * ((nthr + 63) / 64);
+      lv.push_back({len, 1, 1});
+      nthr = len + 1;            // one lane per slot, shifted by one
+      if (nthr <= 64) break;     // a single wave: final
     }
   }
+  const size_t l1_threads = (m + L1 - 1) / L1;
   const size_t total_buckets = (size_t)g.nbuckets * nsets_all;
-  const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : 8u, g.nbuckets);
+  // buckets per thread in the reduction: 8 once that still fills the chip (2^19 buckets), else 4 (measured)
+  const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : (total_buckets >= ((size_t)1 << 19) ? 8u : 4u),
+                              g.nbuckets);
   const u32 chunks_per_win = g.nbuckets / LB;
   const size_t total_chunks = (size_t)chunks_per_win * nsets_all;
 
@@ -547,11 +602,12 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   const size_t o_keys0 = take(m * 4), o_vals0 = take(m * 4), o_keys1 = take(m * 4), o_vals1 = take(m * 4);
   const size_t o_sort = take(sort_tmp);
   const size_t o_buckets = take(total_buckets * 256);
-  std::vector<size_t> o_pkeys(lens.size()), o_ppts(lens.size());
-  for (size_t i = 1; i < lens.size(); ++i) {
-    o_pkeys[i] = take(lens[i] * 4);
-    o_ppts[i] = take(lens[i] * 256);
+  std::vector<size_t> o_pkeys(lv.size()), o_ppts(lv.size());
+  for (size_t i = 1; i < lv.size(); ++i) {
+    o_pkeys[i] = take(lv[i].len * 4);
+    o_ppts[i] = take(lv[i].len * 256);
   }
+  const size_t o_heads = take(lv.size() > 1 ? l1_threads * 256 : 0);
   const size_t o_red = take(total_chunks * 256);
   const size_t o_red2 = take((total_chunks / 256 + nsets_all) * 256);
   const size_t o_win = take((size_t)nsets_all * 256);
@@ -589,14 +645,12 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   a.bases = (const u32x4*)(bases->table_c ? bases->d_table : bases->d_xy);
   a.trash = g.trash;
   a.buckets = buckets;
-  for (size_t lvl = 0; lvl < lens.size(); ++lvl) {
-    const bool last = (lvl + 1 == lens.size());
-    a.len = lens[lvl];
-    a.chunk = lvl == 0 ? L1 : LN;
-    a.offset = lvl == 0 ? 0 : LN_OFF;
-    if (last) {  // one thread takes what is left
-      a.chunk = (u32)std::max<size_t>(a.chunk, a.len + a.offset);
-    }
+  a.head_pts = (u32x4*)(ws + o_heads);
+  for (size_t lvl = 0; lvl < lv.size(); ++lvl) {
+    const bool last = (lvl + 1 == lv.size());
+    a.len = lv[lvl].len;
+    a.chunk = lv[lvl].chunk;
+    a.offset = lv[lvl].offset;
     a.final_level = last ? 1u : 0u;
     if (lvl == 0) {
       a.keys = keys1;
@@ -611,6 +665,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
     const size_t nthr = (a.len + a.offset + a.chunk - 1) / a.chunk;
     const unsigned blocks = (unsigned)((nthr + 127) / 128);
+    if (lvl > 0 && last && nthr > 64) return set_err(ctx, PM_ERR_BAD_ARG, "internal: final MSM level wider than a wave");
     {
       ProfScope prof(ctx, st, lvl == 0 ? "msm_accumulate_l1" : "msm_accumulate_ln");
       if (lvl == 0)
@@ -751,8 +806,12 @@ extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t win
   const size_t n = bases->n;
   u32 lg = 0;
   while (((size_t)2 << lg) <= std::max<size_t>(n, 1)) ++lg;
-  // default: about one bucket per point (measured best at 2^20: c = 20), at most 2^19 buckets
-  const u32 c = window_bits ? window_bits : std::min<u32>(20u, std::max<u32>(12u, lg));
+  // default (measured, profiles/r02_msm_sweep.txt): the accumulate kernel does n * ceil(256 / c) additions and
+  // the bucket reduction ~60 sequential group operations whatever the bucket count, so the window grows
+  // with n -- 2^17 points (an 8-way shard of 2^20): c = 16, 1.4 ms; 2^20: c = 20, 4.1 ms; 2^21: c = 20,
+  // 6.8 ms.  Only widths whose top window still spans several bits are used (13 -> 8 bits, 16 -> 15,
+  // 20 -> 15): a top window of 1-4 bits (c = 17, 18, 21) puts n / 8 points into each of a few buckets.
+  const u32 c = window_bits ? window_bits : (lg <= 15 ? 13u : (lg <= 18 ? 16u : 20u));
   if (c < 8 || c > 22) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..22");
   if (n == 0) return PM_OK;
   const u32 nwin = (256 + c - 1) / c;

@@ -111,7 +111,12 @@ static int build_pow_table(pm_ctx* ctx, void** out, const HFr& base, const HFr& 
   to_limbs(c.one, host::one(host::FR()));
   hipLaunchKernelGGL(pow_table_kernel, dim3((count + 255) / 256), dim3(256), 0, st, (u32x4*)*out, c,
                      count, stride);
-  PM_HIP(ctx, hipGetLastError());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    (void)hipFree(*out);
+    *out = nullptr;
+    return set_err(ctx, PM_ERR_HIP, std::string("pow_table_kernel: ") + hipGetErrorString(e));
+  }
   return PM_OK;
 }
 
@@ -163,20 +168,31 @@ static int get_domain_tables(pm_ctx* ctx, int dir, unsigned log_n, bool need_cos
   const host::Field<4>& F = host::FR();
   t.lh = (log_n + 1) / 2;
   const u32 n_lo = 1u << t.lh, n_hi = 1u << (log_n - t.lh);
-  if (!t.tw_lo) {
+  // a pair of tables is published only when both were built: a failed second allocation must not
+  // leave a half-initialised entry for the next call to launch with
+  auto build_pair = [&](const HFr& base, void** lo_out, void** hi_out) -> int {
+    void *lo = nullptr, *hi = nullptr;
+    int rc = build_pow_table(ctx, &lo, base, host::one(F), n_lo, 1, st);
+    if (!rc) rc = build_pow_table(ctx, &hi, base, host::one(F), n_hi, n_lo, st);
+    if (rc) {
+      if (lo) (void)hipFree(lo);
+      if (hi) (void)hipFree(hi);
+      return rc;
+    }
+    *lo_out = lo;
+    *hi_out = hi;
+    return PM_OK;
+  };
+  if (!t.tw_lo || !t.tw_hi) {
     HFr w = domain_gen(log_n);
     if (dir) w = host::inv(w, F);
-    int rc = build_pow_table(ctx, &t.tw_lo, w, host::one(F), n_lo, 1, st);
-    if (rc) return rc;
-    rc = build_pow_table(ctx, &t.tw_hi, w, host::one(F), n_hi, n_lo, st);
+    int rc = build_pair(w, &t.tw_lo, &t.tw_hi);
     if (rc) return rc;
   }
-  if (need_coset && !t.cs_lo) {
+  if (need_coset && (!t.cs_lo || !t.cs_hi)) {
     HFr g = host::from_u64(host::FR_GENERATOR, F);
     if (dir) g = host::inv(g, F);
-    int rc = build_pow_table(ctx, &t.cs_lo, g, host::one(F), n_lo, 1, st);
-    if (rc) return rc;
-    rc = build_pow_table(ctx, &t.cs_hi, g, host::one(F), n_hi, n_lo, st);
+    int rc = build_pair(g, &t.cs_lo, &t.cs_hi);
     if (rc) return rc;
   }
   *out = &t;
@@ -199,6 +215,41 @@ static void fill_consts(NttConsts& c, int dir, unsigned log_n) {
     to_limbs(c.scale, host::one(F));
 }
 
+// Inter-pass twiddle table of pass i (N x 36 B, laid out like the wide data): built on first use for
+// the plan in force, rebuilt when the tunables changed the plan.
+static unsigned plan_wide_glog(const Plan& plan) {
+  int min_lt = 3;
+  for (int i = 0; i < plan.npass; ++i) min_lt = std::min(min_lt, plan.LT[i]);
+  return (unsigned)std::max(min_lt, 2);
+}
+static int get_pass_tw(pm_ctx* ctx, NttDomainTables* dt, int i, bool last, int dir, unsigned log_n, unsigned log_ns,
+                       int S, unsigned wide_glog, const NttConsts& kc, hipStream_t st, void** out) {
+  const size_t n = (size_t)1 << log_n;
+  const unsigned key = (((((log_ns << 8) | (unsigned)S) << 1) | (last ? 1u : 0u)) << 2) | wide_glog;
+  if (dt->pass_tw[i] && dt->pass_tw_key[i] != key) {  // the plan changed (tunables): rebuild
+    PM_HIP(ctx, hipDeviceSynchronize());
+    PM_HIP(ctx, hipFree(dt->pass_tw[i]));
+    dt->pass_tw[i] = nullptr;
+  }
+  if (!dt->pass_tw[i]) {
+    void* t = nullptr;
+    PM_HIP(ctx, hipMalloc(&t, n * 36));
+    NttConsts c2 = kc;
+    if (!(last && dir)) memcpy(c2.scale, kc.one, sizeof c2.scale);  // only the inverse's last pass carries n^-1
+    hipLaunchKernelGGL(pass_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, c2, log_n, log_ns,
+                       (u32)S, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, wide_glog);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      (void)hipFree(t);
+      return set_err(ctx, PM_ERR_HIP, std::string("pass_tw_kernel: ") + hipGetErrorString(e));
+    }
+    dt->pass_tw[i] = t;
+    dt->pass_tw_key[i] = key;
+  }
+  *out = dt->pass_tw[i];
+  return PM_OK;
+}
+
 // ------------------------------------------------------------------ execution
 int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
             size_t out_stride, unsigned log_n, unsigned batch, unsigned flags, hipStream_t st) {
@@ -211,6 +262,10 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     return set_err(ctx, PM_ERR_BAD_ARG, "batch strides shorter than the vectors");
   if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET)) return set_err(ctx, PM_ERR_BAD_ARG, "unknown flags");
   PM_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    int orc = order_on(ctx, ctx->ord_ntt, st);   // scratch vectors and lazily built tables are shared by all streams
+    if (orc) return orc;
+  }
   const int dir = (flags & PM_NTT_INVERSE) ? 1 : 0;
   const bool coset = (flags & PM_NTT_COSET) != 0;
 
@@ -272,11 +327,7 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
   const void* src = d_in;
   unsigned log_ns = 0;
   a.wide_total = (unsigned long long)batch * n;
-  {
-    int min_lt = 3;
-    for (int i = 0; i < plan.npass; ++i) min_lt = std::min(min_lt, plan.LT[i]);
-    a.wide_glog = (u32)std::max(min_lt, 2);
-  }
+  a.wide_glog = plan_wide_glog(plan);
   for (int i = 0; i < plan.npass; ++i) {
     const bool last = (i == plan.npass - 1);
     const int S = plan.S[i], LT = plan.LT[i];
@@ -301,30 +352,20 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     a.pass_tw = nullptr;
     u32 tw_flag = 0;
     if (i > 0 && direct_tw) {
-      const unsigned key = (((((log_ns << 8) | (unsigned)S) << 1) | (last ? 1u : 0u)) << 2) | a.wide_glog;
-      if (dt->pass_tw[i] && dt->pass_tw_key[i] != key) {  // the plan changed (tunables): rebuild
-        PM_HIP(ctx, hipStreamSynchronize(st));
-        PM_HIP(ctx, hipFree(dt->pass_tw[i]));
-        dt->pass_tw[i] = nullptr;
-      }
-      if (!dt->pass_tw[i]) {
-        dt->pass_tw_key[i] = key;
-        PM_HIP(ctx, hipMalloc(&dt->pass_tw[i], n * 36));
-        NttConsts c2 = kc;
-        if (!(last && dir)) memcpy(c2.scale, kc.one, sizeof c2.scale);  // only the inverse's last pass carries n^-1
-        hipLaunchKernelGGL(pass_tw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dt->pass_tw[i], c2,
-                           log_n, log_ns, (u32)S, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, a.wide_glog);
-        PM_HIP(ctx, hipGetLastError());
-      }
-      a.pass_tw = dt->pass_tw[i];
+      void* ptw = nullptr;
+      rc = get_pass_tw(ctx, dt, i, last, dir, log_n, log_ns, S, a.wide_glog, kc, st, &ptw);
+      if (rc) return rc;
+      a.pass_tw = ptw;
       tw_flag = PASS_DIRECT_TW;
     }
     a.flags = (i == 0 ? pre : 0u) | post_i | tw_flag | (ctx->opt_ntt_xcd ? PASS_XCD_REMAP : 0u);
     const unsigned threads = r4 ? pass4_threads(S, LT) : std::max(64u, (1u << (S + LT)) / 8);
     const size_t lds = r4 ? pass4_lds(S, LT) : pass_lds_bytes(S, LT);
-    if (lds > 64 * 1024)
+    if (lds > 64 * 1024 && !ctx->big_lds_set[(const void*)fn]) {   // once per kernel, not per launch
       PM_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
+      ctx->big_lds_set[(const void*)fn] = true;
+    }
     const unsigned blocks = (unsigned)(n >> (S + LT));
     {
       static const char* kRoleName[4] = {"ntt_pass_single", "ntt_pass_first", "ntt_pass_middle", "ntt_pass_last"};
@@ -375,15 +416,34 @@ extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
     return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   if (log_n == 0) return PM_OK;
+  int orc = order_on(ctx, ctx->ord_ntt, ctx->stream);
+  if (orc) return orc;
+  // exactly the tables ntt_run() would build on the first transform of this size: domain and coset
+  // tables, the step tables of the kernels the plan picks (radix-4 or radix-8 family), and the
+  // inter-pass twiddle tables of both directions
   Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix);
+  const unsigned wide_glog = plan_wide_glog(plan);
   for (int dir = 0; dir < 2; ++dir) {
     NttDomainTables* dt;
     int rc = get_domain_tables(ctx, dir, log_n, true, &dt, ctx->stream);
     if (rc) return rc;
+    NttConsts kc;
+    fill_consts(kc, dir, log_n);
+    unsigned log_ns = 0;
     for (int i = 0; i < plan.npass; ++i) {
+      const bool last = (i == plan.npass - 1);
+      const int role = plan.npass == 1 ? ROLE_SINGLE : (i == 0 ? ROLE_FIRST : (last ? ROLE_LAST : ROLE_MIDDLE));
+      const bool r4 = ctx->opt_ntt_radix == 4 && find_pass4(plan.S[i], plan.LT[i], role) != nullptr;
       void* stw;
-      rc = get_step_table(ctx, dir, (unsigned)plan.S[i], &stw, ctx->stream);
+      rc = r4 ? get_step4_table(ctx, dir, (unsigned)plan.S[i], &stw, ctx->stream)
+              : get_step_table(ctx, dir, (unsigned)plan.S[i], &stw, ctx->stream);
       if (rc) return rc;
+      if (i > 0 && log_n <= 26) {
+        void* ptw;
+        rc = get_pass_tw(ctx, dt, i, last, dir, log_n, log_ns, plan.S[i], wide_glog, kc, ctx->stream, &ptw);
+        if (rc) return rc;
+      }
+      log_ns += (unsigned)plan.S[i];
     }
   }
   PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
