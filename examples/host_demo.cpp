@@ -96,10 +96,11 @@ int main() {
     const size_t gn = 64;
     const Fr zero{0, 0, 0, 0}, one = EvaluationDomain::one();
     const Fr minus_one = DevicePolynomial(ctx, std::vector<Fr>{zero}).sub(DevicePolynomial(ctx, std::vector<Fr>{one})).to_host()[0];
-    std::array<std::vector<Fr>, 6> sel;
-    for (auto& v : sel) v.assign(gn, zero);
+    std::array<std::vector<Fr>, PM_PLONK_SELECTORS> sel;   // the widget selectors stay empty = identically zero
+    for (int s2 = 0; s2 < 7; ++s2) sel[s2].assign(gn, zero);
     sel[1].assign(gn, one);                                 // q_l
     sel[3].assign(gn, minus_one);                           // q_o
+    sel[6].assign(gn, one);                                 // q_arith
     std::vector<int64_t> sigma(4 * gn);
     for (size_t p2 = 0; p2 < 4 * gn; ++p2) sigma[p2] = (int64_t)p2;
     std::vector<Fr> wit(4 * gn);
@@ -108,8 +109,8 @@ int main() {
       wit[gn + i] = random_fr();
       wit[3 * gn + i] = random_fr();
     }
-    ProverKey pk(ctx, sel, sigma);
     CommitKey ck64(ctx, std::vector<G1Affine>(pts.begin(), pts.begin() + gn));
+    ProverKey pk(ctx, sel, sigma, ck64);
     DevicePolynomial dwit(ctx, wit);
     Proof proof = pk.prove(ck64, dwit);
     Proof proof2 = pk.prove(ck64, dwit);
@@ -117,7 +118,14 @@ int main() {
     EvaluationDomain dom64(ctx, gn);
     REQUIRE(proof.commitments[0] == ck64.commit(dom64.ifft(std::vector<Fr>(wit.begin(), wit.begin() + gn))));   // [a]
     REQUIRE(proof.commitments[0] == proof.commitments[2]);  // a = c as polynomials
-    REQUIRE(pk.prove(ck64, dwit, nullptr, "other").challenges[0] != proof.challenges[0]);
+    REQUIRE(proof.bytes == proof2.bytes);
+    ProverKey pk_other(ctx, sel, sigma, ck64, "other");      // another transcript label: other challenges, same [a]
+    Proof proof3 = pk_other.prove(ck64, dwit);
+    REQUIRE(proof3.challenges[0] != proof.challenges[0] && proof3.commitments[0] == proof.commitments[0]);
+    REQUIRE(pk.verifier_key()[1] == ck64.commit(dom64.ifft(sel[1])));                                            // [q_l]
+    // a public input at gate 3 (PI enters the gate equation: a - c + PI = 0 no longer holds, but the
+    // transcript must see it): other challenges than without
+    REQUIRE(pk.prove(ck64, dwit, {PublicInput{3, one}}).challenges[0] != proof.challenges[0]);
     std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial, ProverKey over %s)\n", pm_version());
     return 0;
   } catch (const Error& e) {

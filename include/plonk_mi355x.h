@@ -64,7 +64,9 @@ typedef enum {
   PM_ERR_OOM = -3,
   PM_ERR_HIP = -4,
   PM_ERR_NO_DEVICE = -5,
-  PM_ERR_LENGTH = -6            /* in_len > 2^log_n, or n > number of uploaded bases */
+  PM_ERR_LENGTH = -6,           /* in_len > 2^log_n, or n > number of uploaded bases */
+  PM_ERR_EXCHANGE = -7,         /* a multi-GPU exchange (callback or RCCL) failed or a peer gave up */
+  PM_ERR_BUSY = -8              /* the prover key's workspace is in use by another proof */
 } pm_status;
 
 /* pm_fr_ntt flags */
@@ -178,6 +180,11 @@ int pm_fr_vec_op_dev(pm_ctx* ctx, int op, const void* d_a, const void* d_b, size
 /* Polynomial::evaluate: out = sum_i coeffs[i] * point^i.  Blocks until `out` is on the host. */
 int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t point[4],
                             uint64_t out[4], void* hip_stream);
+/* The same for k <= PM_LINCOMB_MAX polynomials of n coefficients at ONE point (d_polys: host array of device
+ * pointers, out: k x 4 limbs): one pass of kernels and a single host synchronisation -- the prover opens
+ * 15 polynomials at z and 4 at z w. */
+int pm_fr_poly_evaluate_many_dev(pm_ctx* ctx, uint32_t k, const void* const* d_polys, size_t n, const uint64_t point[4],
+                                 uint64_t* out, void* hip_stream);
 /* Polynomial::ruffini: quotient of coeffs(X) / (X - z), n-1 coefficients into d_out (the
  * remainder coeffs(z) is dropped, as upstream).  Not in place.  Asynchronous on the stream. */
 int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], void* d_out,
@@ -221,11 +228,22 @@ int pm_plonk_perm_terms_dev(pm_ctx* ctx, const pm_plonk_perm_args* args, size_t 
                             void* hip_stream);
 
 /* Quotient numerator divided by Z_H, pointwise on the 4n coset (x_i = g w_4n^i, i < 4n):
- *   t[i] = zh_inv[i mod 4] * ( q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + pi
+ *   t[i] = zh_inv[i mod 4] * ( q_arith (q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c) + pi
+ *          + q_range R + q_logic L + q_fixed_group_add F + q_variable_group_add V
  *          + alpha   ( z[i]   prod_j (w_j + beta k_j x_i + gamma)
  *                    - z[i+4] prod_j (w_j + beta sigma_j + gamma) )
  *          + alpha^2 ( z[i] - 1 ) l1[i] )
- * (index i+4 wraps: z(w X) on the 4n coset).  coset_ifft of t gives the quotient polynomial. */
+ * (index i+4 wraps: f(w X) on the 4n coset).  R, L, F, V are dusk-plonk 0.8's widget identities
+ * (proof_system::widget::{range, logic, ecc::scalar_mul::fixed_base, ecc::curve_addition}) over the
+ * row's wires and a_next, b_next, d_next, each times its separation challenge:
+ *   R = s (delta(c - 4d) + k delta(b - 4c) + k^2 delta(a - 4b) + k^3 delta(d_next - 4a)),  k = s^2,
+ *       delta(f) = f (f-1)(f-2)(f-3)
+ *   L = s (delta(qa) + k delta(qb) + k^2 delta(qd) + k^3 (c - qa qb) + k^4 delta_xor_and(qa, qb, c, qd, q_c)),
+ *       qa = a_next - 4a, qb = b_next - 4b, qd = d_next - 4d
+ *   F = one round of JubJub fixed-base scalar multiplication (table point in q_l, q_r, q_c)
+ *   V = JubJub addition (a, b) + (c, d) = (a_next, b_next), d_next = a d
+ * coset_ifft of t gives the quotient polynomial.  A NULL q_arith means the constant 1, a NULL widget
+ * selector means identically zero (that widget is not evaluated). */
 typedef struct pm_plonk_quotient_args {
   const void* wires[4];
   const void* z;
@@ -242,42 +260,98 @@ typedef struct pm_plonk_quotient_args {
   uint64_t alpha[4], beta[4], gamma[4];
   uint64_t k[3][4];
   uint64_t zh_inv[4][4];  /* 1 / (x_i^n - 1), which only depends on i mod 4 */
+  const void* q_arith;                /* NULL = 1 */
+  const void* q_range;                /* NULL = 0, as the three below */
+  const void* q_logic;
+  const void* q_fixed_group_add;
+  const void* q_variable_group_add;
+  uint64_t range_sep[4], logic_sep[4], fixed_sep[4], var_sep[4];   /* the widgets' separation challenges */
 } pm_plonk_quotient_args;
 int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, void* d_out,
                           void* hip_stream);
 
 /* ---- the whole prover behind one call ------------------------------------------------------------ */
-/* Prover::prove_with_preprocessed (dusk-plonk 0.8.2, ref:Cargo.toml:19) for the arithmetic gate and the
- * 4-wire permutation, sequenced inside the library: five rounds, 11 commitments, 10 evaluations, Merlin
- * transcript (labels: "w_a".."w_d", "beta", "gamma", "z", "alpha", "t_1".."t_4", "z", "<name>_eval", "v",
- * "w_z", "w_zw", "u" -- upstream's label strings are not available here).  plonk-prototype_amd/prover.py is
- * the same sequence in Python; the two produce identical proofs. */
+/* Prover::{preprocess, prove_with_preprocessed} of dusk-plonk 0.8.2 (ref:Cargo.toml:19) sequenced inside the
+ * library: 11 selector polynomials (the gate kinds the reference's gadgets emit: arithmetic, range, logic,
+ * fixed-base scalar multiplication, variable-base curve addition -- ref:src/zk/gadgets.rs:34,37,40,88-91,211),
+ * the 4-wire permutation, five rounds, 11 commitments, the 16 evaluations of dusk's Proof, a Merlin
+ * transcript seeded with the verifier key.  Transcript (labels restated from the published 0.8 design,
+ * unpinned): Transcript::new(label); q_m q_l q_r q_o q_c q_4 q_arith q_range q_logic q_variable_group_add
+ * q_fixed_group_add left_sigma right_sigma out_sigma fourth_sigma; "dom-sep" = "circuit_size", "n";
+ * w_l w_r w_o w_4; beta (re-absorbed), gamma; z; alpha and the four "... separation challenge"s; t_1..t_4;
+ * z; the 17 "<name>_eval" scalars; "aggregate_witness" twice; w_z, w_z_w. */
+#define PM_PLONK_SELECTORS 11   /* q_m q_l q_r q_o q_c q_4 q_arith q_range q_logic q_fixed_group_add q_variable_group_add */
+#define PM_PLONK_VK_POINTS 15   /* the selector commitments in that order, then sigma_1..4 */
+#define PM_PLONK_EVALS 17       /* a b c d a_next b_next d_next sigma_1 sigma_2 sigma_3 q_arith q_c q_l q_r z_next t r */
+#define PM_PLONK_CHALLENGES 10  /* beta gamma alpha range_sep logic_sep fixed_sep var_sep z aw aw_shifted */
+#define PM_PLONK_PROOF_BYTES 1040
+/* prove flag: also absorb the public inputs (count, then position and value of each) before round 1.
+ * dusk-plonk 0.8.2 does not (its transcript never sees them); without it the statement is not bound to the
+ * challenges.  Off = byte-compatible with the restated upstream transcript. */
+#define PM_PLONK_BIND_PUBLIC_INPUTS 1u
 typedef struct pm_prover_key pm_prover_key;
 typedef struct pm_plonk_proof {
-  uint64_t commitments[11][12];  /* a b c d z t_1 t_2 t_3 t_4 w_z w_zw, affine, (0, 0) = identity */
-  uint64_t evaluations[10][4];   /* a b c d sigma_1 sigma_2 sigma_3 z_next t r, Montgomery limbs */
-  uint64_t challenges[6][4];     /* beta gamma alpha z v u (recomputable from the transcript) */
+  uint64_t commitments[11][12];                  /* a b c d z t_1 t_2 t_3 t_4 w_z w_zw, affine, (0, 0) = identity */
+  uint64_t evaluations[PM_PLONK_EVALS][4];       /* transcript order (above), Montgomery limbs; t is not part of dusk's Proof */
+  uint64_t challenges[PM_PLONK_CHALLENGES][4];   /* recomputable from the transcript */
 } pm_plonk_proof;
-/* ProverKey: selectors[s] = n evaluations on H of q_m q_l q_r q_o q_4 q_c (host memory); sigma_index[j n + i] =
- * position (j' n + i') that follows wire j of gate i in its copy cycle.  n a power of two >= 4.  Builds
- * the coefficient and 4n-coset forms on the device and the per-proof workspace (about 90 n x 32 bytes). */
-int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[6], const int64_t* sigma_index, size_t n,
-                        pm_prover_key** out);
+/* ProverKey: selectors[s] = n evaluations on H (host memory) in the order of PM_PLONK_SELECTORS, NULL =
+ * identically zero; sigma_index[j n + i] = position (j' n + i') that follows wire j of gate i in its copy
+ * cycle.  n a power of two >= 4.  Builds the coefficient forms, the 4n-coset forms the quotient needs
+ * (trivial selectors -- q_arith = 1, a widget selector = 0 -- are recognised and skipped) and the per-proof
+ * workspace (about 90 n x 32 bytes). */
+int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[PM_PLONK_SELECTORS], const int64_t* sigma_index,
+                        size_t n, pm_prover_key** out);
 void pm_plonk_key_free(pm_ctx* ctx, pm_prover_key* key);
-/* d_witness: device memory, [a | b | c | d] wire values, 4n Fr.  d_public_inputs: device memory, n
- * evaluations of PI on H, or NULL for none.  commit_key: at least n resident bases (pm_g1_bases_upload /
- * pm_g1_bases_from_dev, ideally with pm_g1_bases_precompute).  transcript_label NULL = "plonk". */
+/* Commits to the 15 polynomials of the key (the G1 part of dusk's VerifierKey) and seeds the key's base
+ * transcript with them (Prover::preprocess).  Must run once before the first proof; commit_key: at least n
+ * resident bases.  verifier_key_out: PM_PLONK_VK_POINTS affine points, may be NULL.  transcript_label NULL =
+ * "plonk". */
+int pm_plonk_key_commit(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, const char* transcript_label,
+                        uint64_t (*verifier_key_out)[12]);
+int pm_plonk_verifier_key(const pm_prover_key* key, uint64_t (*out)[12]);
+/* d_witness: device memory, [a | b | c | d] wire values, 4n Fr.  Public inputs: n_pi (position < n, value)
+ * pairs in host memory -- the dense PI vector of dusk's construct_dense_pi_vec is built on the device.
+ * commit_key: at least n resident bases (pm_g1_bases_upload / pm_g1_bases_from_dev, ideally with
+ * pm_g1_bases_precompute).  One proof at a time per key (PM_ERR_BUSY otherwise). */
 int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, const void* d_witness,
-                   const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out);
-/* The same proof with the SRS split over the GPUs of a node (BASELINE.json configs[4]): every rank calls
- * this with the same witness and its own slice of the commit key -- bases for coefficients
- * [first_coefficient, first_coefficient + pm_g1_bases_len(slice)) -- and `exchange` turns this rank's k
- * partial points (k x 18 limbs, in place) into the sums over all ranks: an all-gather of k x 144 bytes
- * (ncclAllGather over xGMI) followed by pm_g1_fold per point.  Returns non-zero to abort. */
+                   const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
+                   pm_plonk_proof* out);
+/* Proof::to_bytes: 11 x 48-byte compressed G1, then the 16 scalars of ProofEvaluations::to_bytes. */
+int pm_plonk_proof_to_bytes(const pm_plonk_proof* proof, uint8_t out[PM_PLONK_PROOF_BYTES]);
+/* The same with the SRS split over the GPUs of a node (BASELINE.json configs[4]): every rank calls this with
+ * the same witness and its own slice of the commit key -- bases for coefficients [first_coefficient,
+ * first_coefficient + pm_g1_bases_len(slice)) -- and `exchange` turns this rank's k partial points (k x 18
+ * limbs, in place) into the sums over all ranks: an all-gather of k x 144 bytes followed by pm_g1_fold per
+ * point.  exchange = NULL uses the context's RCCL communicator (pm_comm_init).  A callback is also entered
+ * with k = 0 when this rank's local work failed: it must tell the peers (so that none blocks) and return
+ * non-zero; a non-zero return aborts with PM_ERR_EXCHANGE. */
 typedef int (*pm_exchange_fn)(void* user, uint64_t* xyz, uint32_t k);
+int pm_plonk_key_commit_sharded(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key_slice,
+                                size_t first_coefficient, pm_exchange_fn exchange, void* user,
+                                const char* transcript_label, uint64_t (*verifier_key_out)[12]);
 int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key_slice, size_t first_coefficient,
-                           const void* d_witness, const void* d_public_inputs, const char* transcript_label,
-                           pm_exchange_fn exchange, void* user, pm_plonk_proof* out);
+                           const void* d_witness, const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi,
+                           uint32_t flags, pm_exchange_fn exchange, void* user, pm_plonk_proof* out);
+
+/* ---- the exchange step inside the library (SURVEY.md sections 8b, 8e) ------------------------------- */
+/* One process per GPU, one pm_ctx per process.  Rank 0 makes the id and hands its 128 bytes to the other ranks
+ * out of band (MPI, a file, the host runtime's own broadcast); every rank then calls pm_comm_init, which is
+ * collective (ncclCommInitRank over xGMI).  RCCL is bound at run time (dlopen of librccl.so.1).
+ * pm_g1_allgather_fold: every rank passes its k <= PM_COMM_MAX_POINTS partial points (k x 18 limbs,
+ * projective); on return each holds the sums over all ranks -- one ncclAllGather of a fixed 2312-byte message
+ * per rank, then pm_g1_fold per point: an all-reduce under the group law (RCCL has no such reduction).  k = 0
+ * is the abort marker of a rank whose local work failed: it still takes part, and the call returns
+ * PM_ERR_EXCHANGE on every rank instead of leaving the peers blocked. */
+#define PM_COMM_ID_BYTES 128
+#define PM_COMM_MAX_POINTS 16
+int pm_comm_unique_id(uint8_t id[PM_COMM_ID_BYTES]);
+int pm_comm_init(pm_ctx* ctx, const uint8_t id[PM_COMM_ID_BYTES], int rank, int world);
+int pm_comm_destroy(pm_ctx* ctx);
+int pm_comm_info(const pm_ctx* ctx, int* rank, int* world);
+int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k);
+/* test hook: the fold step on `world` messages of 1 + 16 x 18 words ([count | points]) given by the caller */
+int pm_test_fold_gathered(const uint64_t* msgs, int world, uint32_t k, uint64_t* out_xyz);
 
 /* Keccak-f[1600] on a 200-byte state (host; the permutation under the Merlin / STROBE-128 transcript
  * the prover derives its challenges from -- merlin is a dependency of dusk-plonk, ref:Cargo.toml:19). */

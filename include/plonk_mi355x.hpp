@@ -225,42 +225,70 @@ class DevicePolynomial {
 };
 
 // ------------------------------------------------------------------------------------------------
-// dusk_plonk::proof_system::{ProverKey, Prover::prove_with_preprocessed, Proof} for the arithmetic gate
-// and the 4-wire permutation: one library call per proof (pm_plonk_prove), everything resident in HBM.
+// dusk_plonk::proof_system::{ProverKey, Prover::preprocess, Prover::prove_with_preprocessed, Proof}: the 11
+// selector polynomials of dusk-plonk 0.8 (arithmetic, range, logic, fixed-base, variable-base) and the
+// 4-wire permutation; one library call per proof (pm_plonk_prove), everything resident in HBM.
 struct Proof {
-  std::array<G1Affine, 11> commitments;  // a b c d z t_1 t_2 t_3 t_4 w_z w_zw
-  std::array<Fr, 10> evaluations;        // a b c d sigma_1 sigma_2 sigma_3 z_next t r
-  std::array<Fr, 6> challenges;          // beta gamma alpha z v u
+  std::array<G1Affine, 11> commitments;                  // a b c d z t_1 t_2 t_3 t_4 w_z w_zw
+  std::array<Fr, PM_PLONK_EVALS> evaluations;            // transcript order, see plonk_mi355x.h
+  std::array<Fr, PM_PLONK_CHALLENGES> challenges;
+  std::array<uint8_t, PM_PLONK_PROOF_BYTES> bytes;       // Proof::to_bytes
+};
+struct PublicInput {
+  uint64_t position;   // gate index
+  Fr value;
 };
 
 class ProverKey {
  public:
-  // selectors: q_m q_l q_r q_o q_4 q_c, n evaluations on H each; sigma_index[j n + i] = successor position
-  ProverKey(Context& ctx, const std::array<std::vector<Fr>, 6>& selectors, const std::vector<int64_t>& sigma_index)
+  // selectors: q_m q_l q_r q_o q_c q_4 q_arith q_range q_logic q_fixed_group_add q_variable_group_add, n
+  // evaluations on H each (an empty vector = identically zero); sigma_index[j n + i] = successor position.
+  // The verifier key is committed with `ck` and seeds the transcript every proof starts from.
+  ProverKey(Context& ctx, const std::array<std::vector<Fr>, PM_PLONK_SELECTORS>& selectors,
+            const std::vector<int64_t>& sigma_index, const CommitKey& ck, const char* transcript_label = nullptr)
       : ctx_(&ctx), n_(selectors[0].size()) {
-    const uint64_t* ptrs[6];
-    for (int s = 0; s < 6; ++s) {
+    const uint64_t* ptrs[PM_PLONK_SELECTORS];
+    for (int s = 0; s < PM_PLONK_SELECTORS; ++s) {
+      if (selectors[s].empty()) {
+        ptrs[s] = nullptr;
+        continue;
+      }
       if (selectors[s].size() != n_ || n_ == 0) throw Error(PM_ERR_LENGTH, "selectors differ in length");
       ptrs[s] = selectors[s][0].data();
     }
     if (sigma_index.size() != 4 * n_) throw Error(PM_ERR_LENGTH, "sigma_index must have 4n entries");
     ctx.check(pm_plonk_preprocess(ctx.get(), ptrs, sigma_index.data(), n_, &key_));
+    uint64_t vk[PM_PLONK_VK_POINTS][12];
+    int rc = pm_plonk_key_commit(ctx.get(), key_, ck.bases(), transcript_label, vk);
+    if (rc) {
+      pm_plonk_key_free(ctx.get(), key_);
+      key_ = nullptr;
+      ctx.check(rc);
+    }
+    for (int i = 0; i < PM_PLONK_VK_POINTS; ++i) std::copy(vk[i], vk[i] + 12, verifier_key_[i].begin());
   }
   ~ProverKey() { if (key_) pm_plonk_key_free(ctx_->get(), key_); }
   ProverKey(const ProverKey&) = delete;
   ProverKey& operator=(const ProverKey&) = delete;
   size_t n() const { return n_; }
-  // witness: [a | b | c | d] on the device (4n); public_inputs: n evaluations of PI on H or nullptr
-  Proof prove(const CommitKey& ck, const DevicePolynomial& witness, const DevicePolynomial* public_inputs = nullptr,
-              const char* transcript_label = nullptr) const {
+  const std::array<G1Affine, PM_PLONK_VK_POINTS>& verifier_key() const { return verifier_key_; }
+  // witness: [a | b | c | d] on the device (4n)
+  Proof prove(const CommitKey& ck, const DevicePolynomial& witness, const std::vector<PublicInput>& public_inputs = {},
+              bool bind_public_inputs = true) const {
     if (witness.len() != 4 * n_) throw Error(PM_ERR_LENGTH, "the witness must hold 4n wire values");
+    std::vector<uint64_t> pos, val;
+    for (const PublicInput& pi : public_inputs) {
+      pos.push_back(pi.position);
+      val.insert(val.end(), pi.value.begin(), pi.value.end());
+    }
     pm_plonk_proof raw;
-    ctx_->check(pm_plonk_prove(ctx_->get(), key_, ck.bases(), witness.data(), public_inputs ? public_inputs->data() : nullptr,
-                               transcript_label, &raw));
+    ctx_->check(pm_plonk_prove(ctx_->get(), key_, ck.bases(), witness.data(), pos.data(), val.data(), pos.size(),
+                               bind_public_inputs ? PM_PLONK_BIND_PUBLIC_INPUTS : 0u, &raw));
     Proof p;
     for (int i = 0; i < 11; ++i) std::copy(raw.commitments[i], raw.commitments[i] + 12, p.commitments[i].begin());
-    for (int i = 0; i < 10; ++i) std::copy(raw.evaluations[i], raw.evaluations[i] + 4, p.evaluations[i].begin());
-    for (int i = 0; i < 6; ++i) std::copy(raw.challenges[i], raw.challenges[i] + 4, p.challenges[i].begin());
+    for (int i = 0; i < PM_PLONK_EVALS; ++i) std::copy(raw.evaluations[i], raw.evaluations[i] + 4, p.evaluations[i].begin());
+    for (int i = 0; i < PM_PLONK_CHALLENGES; ++i) std::copy(raw.challenges[i], raw.challenges[i] + 4, p.challenges[i].begin());
+    ctx_->check(pm_plonk_proof_to_bytes(&raw, p.bytes.data()));
     return p;
   }
 
@@ -268,6 +296,7 @@ class ProverKey {
   Context* ctx_;
   size_t n_;
   pm_prover_key* key_ = nullptr;
+  std::array<G1Affine, PM_PLONK_VK_POINTS> verifier_key_;
 };
 
 }  // namespace plonk_mi355x

@@ -860,15 +860,130 @@ void orc_plonk_perm_terms(const u64 *const *w, const u64 *const *sig, const u64 
     memcpy(den + 4 * i, b, 32);
   }
 }
-/* Quotient on the 4n coset, x[i] = 7 w_4n^i.  ptrs: w0..w3, z, q_m, q_l, q_r, q_o, q_4, q_c, pi, s0..s3, l1, x
- * (18 arrays of 4n).  t[i] = (gate + alpha (z prod id - z(wX) prod copy) + alpha^2 (z - 1) l1) / (x^n - 1) */
-void orc_plonk_quotient(const u64 *const *p, size_t n, const u64 *alpha, const u64 *beta, const u64 *gamma, u64 *out,
-                        int threads) {
+/* ---- the widget identities of dusk-plonk 0.8 (proof_system::widget::{range, logic, ecc::scalar_mul::fixed_base,
+ * ecc::curve_addition}), restated from the published design: each returns the factor its selector multiplies,
+ * separation challenge included.  Same formulas as oracle/plonk_rounds_oracle.py (the big-int restatement). */
+static void w_delta(u64 *r, const u64 *f) { /* f (f-1)(f-2)(f-3) */
+  u64 c[4], t[4], acc[4];
+  memcpy(acc, f, 32);
+  for (u64 k = 1; k <= 3; ++k) {
+    fr_from_small(c, k);
+    fr_sub(t, f, c);
+    fr_mul(acc, acc, t);
+  }
+  memcpy(r, acc, 32);
+}
+static void w_quad(u64 *r, const u64 *hi, const u64 *lo) { /* hi - 4 lo */
+  u64 four[4], t[4];
+  fr_from_small(four, 4);
+  fr_mul(t, four, lo);
+  fr_sub(r, hi, t);
+}
+static void w_range(u64 *r, const u64 *sep, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *dn) {
+  u64 k[4], kp[4], q[4], t[4], acc[4];
+  fr_mul(k, sep, sep);
+  w_quad(q, c, d); w_delta(acc, q);
+  memcpy(kp, k, 32);
+  w_quad(q, b, c); w_delta(t, q); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(kp, kp, k);
+  w_quad(q, a, b); w_delta(t, q); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(kp, kp, k);
+  w_quad(q, dn, a); w_delta(t, q); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(r, acc, sep);
+}
+static void w_logic(u64 *r, const u64 *sep, const u64 *a, const u64 *an, const u64 *b, const u64 *bn, const u64 *c,
+                    const u64 *d, const u64 *dn, const u64 *qc) {
+  u64 k[4], kp[4], qa[4], qb[4], qd[4], t[4], u[4], acc[4], s[4], in[4], f[4], e[4], bb[4], cst[4];
+  fr_mul(k, sep, sep);
+  w_quad(qa, an, a); w_quad(qb, bn, b); w_quad(qd, dn, d);
+  w_delta(acc, qa);
+  memcpy(kp, k, 32);
+  w_delta(t, qb); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(kp, kp, k);
+  w_delta(t, qd); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(kp, kp, k);
+  fr_mul(t, qa, qb); fr_sub(t, c, t); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(kp, kp, k);
+  /* delta_xor_and(qa, qb, w = c, qd, q_c) */
+  fr_add(s, qa, qb);
+  fr_from_small(cst, 4); fr_mul(in, cst, c);
+  fr_from_small(cst, 18); fr_mul(t, cst, s); fr_sub(in, in, t);
+  fr_from_small(cst, 81); fr_add(in, in, cst);                         /* 4w - 18(a+b) + 81 */
+  fr_mul(in, c, in);
+  fr_mul(t, qa, qa); fr_mul(u, qb, qb); fr_add(t, t, u);
+  fr_from_small(cst, 18); fr_mul(t, cst, t); fr_add(in, in, t);        /* + 18 (a^2 + b^2) */
+  fr_from_small(cst, 81); fr_mul(t, cst, s); fr_sub(in, in, t);
+  fr_from_small(cst, 83); fr_add(in, in, cst);                         /* - 81(a+b) + 83 */
+  fr_mul(f, c, in);
+  fr_add(t, s, qd); fr_from_small(cst, 3); fr_mul(e, cst, t);
+  fr_add(t, f, f); fr_sub(e, e, t);                                    /* 3(a+b+c) - 2f */
+  fr_from_small(cst, 9); fr_mul(bb, cst, qd);
+  fr_from_small(cst, 3); fr_mul(t, cst, s); fr_sub(bb, bb, t);
+  fr_mul(bb, qc, bb);                                                  /* q_c (9c - 3(a+b)) */
+  fr_add(t, bb, e); fr_mul(t, t, kp); fr_add(acc, acc, t);
+  fr_mul(r, acc, sep);
+}
+static void w_edwards_d(u64 *r) {
+  u64 a[4], b[4];
+  fr_from_small(a, 10240); fr_from_small(b, 10241);
+  f_inv(b, b, &FR);
+  fr_mul(a, a, b);
+  u64 z[4] = {0, 0, 0, 0};
+  fr_sub(r, z, a);
+}
+static void w_fixed(u64 *r, const u64 *sep, const u64 *edw, const u64 *a, const u64 *an, const u64 *b, const u64 *bn,
+                    const u64 *c, const u64 *d, const u64 *dn, const u64 *ql, const u64 *qr, const u64 *qc) {
+  u64 k[4], k2[4], k3[4], bit[4], t[4], u[4], acc[4], ya[4], xa[4], dxy[4];
+  fr_mul(k, sep, sep); fr_mul(k2, k, k); fr_mul(k3, k2, k);
+  fr_add(t, d, d); fr_sub(bit, dn, t);
+  fr_sub(t, bit, FR.one); fr_mul(acc, bit, t); fr_add(t, bit, FR.one); fr_mul(acc, acc, t);   /* bit (bit-1)(bit+1) */
+  fr_mul(t, bit, bit); fr_sub(u, qr, FR.one); fr_mul(ya, t, u); fr_add(ya, ya, FR.one);
+  fr_mul(xa, ql, bit);
+  fr_mul(t, bit, qc); fr_sub(t, t, c); fr_mul(t, t, k); fr_add(acc, acc, t);
+  fr_mul(dxy, c, a); fr_mul(dxy, dxy, b); fr_mul(dxy, dxy, edw);
+  fr_mul(t, an, dxy); fr_add(t, an, t); fr_mul(u, a, ya); fr_sub(t, t, u); fr_mul(u, b, xa); fr_sub(t, t, u);
+  fr_mul(t, t, k2); fr_add(acc, acc, t);
+  fr_mul(t, bn, dxy); fr_sub(t, bn, t); fr_mul(u, b, ya); fr_sub(t, t, u); fr_mul(u, a, xa); fr_sub(t, t, u);
+  fr_mul(t, t, k3); fr_add(acc, acc, t);
+  fr_mul(r, acc, sep);
+}
+static void w_var(u64 *r, const u64 *sep, const u64 *edw, const u64 *a, const u64 *an, const u64 *b, const u64 *bn,
+                  const u64 *c, const u64 *d, const u64 *dn) {
+  u64 k[4], k2[4], y1x2[4], y1y2[4], x1x2[4], t[4], u[4], acc[4], dd[4];
+  fr_mul(k, sep, sep); fr_mul(k2, k, k);
+  fr_mul(y1x2, b, c); fr_mul(y1y2, b, d); fr_mul(x1x2, a, c);
+  fr_mul(acc, a, d); fr_sub(acc, acc, dn);
+  fr_mul(dd, dn, y1x2); fr_mul(dd, dd, edw);
+  fr_add(t, dn, y1x2); fr_mul(u, an, dd); fr_add(u, an, u); fr_sub(t, t, u); fr_mul(t, t, k); fr_add(acc, acc, t);
+  fr_add(t, y1y2, x1x2); fr_mul(u, bn, dd); fr_sub(u, bn, u); fr_sub(t, t, u); fr_mul(t, t, k2); fr_add(acc, acc, t);
+  fr_mul(r, acc, sep);
+}
+/* the four widget factors at one row / one set of evaluations: out[0..3] = range, logic, fixed, var */
+void orc_plonk_widget_values(const u64 *seps /* range logic fixed var */, const u64 *row /* a b c d an bn dn ql qr qc */,
+                             u64 *out) {
+  orc_init();
+  u64 edw[4];
+  w_edwards_d(edw);
+  const u64 *a = row, *b = row + 4, *c = row + 8, *d = row + 12, *an = row + 16, *bn = row + 20, *dn = row + 24,
+            *ql = row + 28, *qr = row + 32, *qc = row + 36;
+  w_range(out, seps, a, b, c, d, dn);
+  w_logic(out + 4, seps + 4, a, an, b, bn, c, d, dn, qc);
+  w_fixed(out + 8, seps + 8, edw, a, an, b, bn, c, d, dn, ql, qr, qc);
+  w_var(out + 12, seps + 12, edw, a, an, b, bn, c, d, dn);
+}
+
+/* Quotient on the 4n coset, x[i] = 7 w_4n^i.  ptrs: w0..w3, z, q_m, q_l, q_r, q_o, q_4, q_c, pi, s0..s3, l1, x,
+ * q_arith, q_range, q_logic, q_fixed_group_add, q_variable_group_add (23 arrays of 4n); seps: the range, logic,
+ * fixed-base and variable-base separation challenges.
+ * t[i] = (q_arith arith + widgets + pi + alpha (z prod id - z(wX) prod copy) + alpha^2 (z - 1) l1) / (x^n - 1) */
+void orc_plonk_quotient(const u64 *const *p, size_t n, const u64 *alpha, const u64 *beta, const u64 *gamma,
+                        const u64 *seps, u64 *out, int threads) {
   orc_init();
   const size_t n4 = 4 * n;
   const u64 *w[4] = {p[0], p[1], p[2], p[3]}, *z = p[4], *qm = p[5], *ql = p[6], *qr = p[7], *qo = p[8], *q4 = p[9],
-            *qc = p[10], *pi = p[11], *s[4] = {p[12], p[13], p[14], p[15]}, *l1 = p[16], *x = p[17];
-  u64 bk[4][4], alpha2[4], zh_inv[4][4];
+            *qc = p[10], *pi = p[11], *s[4] = {p[12], p[13], p[14], p[15]}, *l1 = p[16], *x = p[17], *qarith = p[18],
+            *qrange = p[19], *qlogic = p[20], *qfixed = p[21], *qvar = p[22];
+  u64 bk[4][4], alpha2[4], zh_inv[4][4], edw[4];
   const u64 ks[4] = {1, 7, 13, 17};
   for (int j = 0; j < 4; ++j) {
     u64 kj[4];
@@ -876,6 +991,7 @@ void orc_plonk_quotient(const u64 *const *p, size_t n, const u64 *alpha, const u
     fr_mul(bk[j], beta, kj);
   }
   fr_mul(alpha2, alpha, alpha);
+  w_edwards_d(edw);
   for (int j = 0; j < 4 && (size_t)j < n4; ++j) { /* x^n - 1 only depends on i mod 4 */
     u64 e[1] = {(u64)n}, t[4];
     f_pow(t, x + 4 * j, e, 1, &FR);
@@ -886,6 +1002,7 @@ void orc_plonk_quotient(const u64 *const *p, size_t n, const u64 *alpha, const u
   for (size_t i = 0; i < n4; ++i) {
     const size_t nx = (i + 4) % n4;
     const u64 *a = w[0] + 4 * i, *b = w[1] + 4 * i, *c = w[2] + 4 * i, *d = w[3] + 4 * i;
+    const u64 *an = w[0] + 4 * nx, *bn = w[1] + 4 * nx, *dn = w[3] + 4 * nx;
     u64 g[4], t[4], id[4], cp[4];
     fr_mul(t, a, b);
     fr_mul(g, t, qm + 4 * i);
@@ -894,6 +1011,12 @@ void orc_plonk_quotient(const u64 *const *p, size_t n, const u64 *alpha, const u
     fr_mul(t, qo + 4 * i, c); fr_add(g, g, t);
     fr_mul(t, q4 + 4 * i, d); fr_add(g, g, t);
     fr_add(g, g, qc + 4 * i);
+    fr_mul(g, g, qarith + 4 * i);
+    w_range(t, seps, a, b, c, d, dn); fr_mul(t, t, qrange + 4 * i); fr_add(g, g, t);
+    w_logic(t, seps + 4, a, an, b, bn, c, d, dn, qc + 4 * i); fr_mul(t, t, qlogic + 4 * i); fr_add(g, g, t);
+    w_fixed(t, seps + 8, edw, a, an, b, bn, c, d, dn, ql + 4 * i, qr + 4 * i, qc + 4 * i);
+    fr_mul(t, t, qfixed + 4 * i); fr_add(g, g, t);
+    w_var(t, seps + 12, edw, a, an, b, bn, c, d, dn); fr_mul(t, t, qvar + 4 * i); fr_add(g, g, t);
     fr_add(g, g, pi + 4 * i);
     memcpy(id, z + 4 * i, 32);
     memcpy(cp, z + 4 * nx, 32);

@@ -79,7 +79,8 @@ class CpuOracle:
             "orc_fr_batch_inverse_trick": [_u64p, C.c_size_t, C.c_int],
             "orc_plonk_perm_terms": [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, _u64p, _u64p, C.c_size_t, _u64p, _u64p,
                                      C.c_int],
-            "orc_plonk_quotient": [C.POINTER(_u64p), C.c_size_t, _u64p, _u64p, _u64p, _u64p, C.c_int],
+            "orc_plonk_quotient": [C.POINTER(_u64p), C.c_size_t, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_int],
+            "orc_plonk_widget_values": [_u64p, _u64p, _u64p],
         }.items():
             getattr(L, name).restype = None
             getattr(L, name).argtypes = at
@@ -227,13 +228,23 @@ class CpuOracle:
         self.lib.orc_plonk_perm_terms(wp, sp, _ptr(r), _ptr(b), _ptr(g), n, _ptr(num), _ptr(den), threads)
         return num, den
 
-    def plonk_quotient(self, arrays18, n: int, alpha, beta, gamma, threads: int = 1) -> np.ndarray:
-        """arrays18: w0..w3, z, q_m, q_l, q_r, q_o, q_4, q_c, pi, s0..s3, l1, x -- each [4n, 4]."""
-        ptrs, keep = self._ptr_array(arrays18)
-        assert len(keep) == 18 and all(a.size == 16 * n for a in keep)
+    def plonk_quotient(self, arrays23, n: int, alpha, beta, gamma, seps, threads: int = 1) -> np.ndarray:
+        """arrays23: w0..w3, z, q_m, q_l, q_r, q_o, q_4, q_c, pi, s0..s3, l1, x, q_arith, q_range, q_logic,
+        q_fixed_group_add, q_variable_group_add -- each [4n, 4]; seps: [4, 4] separation challenges."""
+        ptrs, keep = self._ptr_array(arrays23)
+        assert len(keep) == 23 and all(a.size == 16 * n for a in keep)
         a, b, g = (np.ascontiguousarray(v, dtype=np.uint64).reshape(4) for v in (alpha, beta, gamma))
+        sp = np.ascontiguousarray(seps, dtype=np.uint64).reshape(16)
         out = np.zeros((4 * n, 4), np.uint64)
-        self.lib.orc_plonk_quotient(ptrs, n, _ptr(a), _ptr(b), _ptr(g), _ptr(out), threads)
+        self.lib.orc_plonk_quotient(ptrs, n, _ptr(a), _ptr(b), _ptr(g), _ptr(sp), _ptr(out), threads)
+        return out
+
+    def plonk_widget_values(self, seps, row) -> np.ndarray:
+        """seps [4, 4]; row [10, 4] = a b c d a_next b_next d_next q_l q_r q_c -> [4, 4] range, logic, fixed, var."""
+        sp = np.ascontiguousarray(seps, dtype=np.uint64).reshape(16)
+        rw = np.ascontiguousarray(row, dtype=np.uint64).reshape(40)
+        out = np.zeros((4, 4), np.uint64)
+        self.lib.orc_plonk_widget_values(_ptr(sp), _ptr(rw), _ptr(out))
         return out
 
     # ----------------------------------------------------------------------- G1

@@ -12,5 +12,5 @@ from .host import (CommitKey, Context, DeviceVector, Error, EvaluationDomain, Po
                    msm_variable_base,
                    g1_fold, g1_to_affine, domain_info, ntt_plan)
 from . import field, prover, srs, synthetic, transcript  # noqa: F401,E402
-from .prover import Circuit, NativeProverKey, Proof, ProverKey, preprocess, prove, prove_native  # noqa: F401,E402
+from .prover import Circuit, Proof, ProverKey, preprocess, prove  # noqa: F401,E402
 from .transcript import Transcript  # noqa: F401,E402

@@ -25,16 +25,23 @@ class QuotientArgs(C.Structure):
                 ("q_r", C.c_void_p), ("q_o", C.c_void_p), ("q_4", C.c_void_p), ("q_c", C.c_void_p),
                 ("pi", C.c_void_p), ("sigmas", C.c_void_p * 4), ("l1", C.c_void_p), ("x", C.c_void_p),
                 ("alpha", C.c_uint64 * 4), ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4),
-                ("k", (C.c_uint64 * 4) * 3), ("zh_inv", (C.c_uint64 * 4) * 4)]
+                ("k", (C.c_uint64 * 4) * 3), ("zh_inv", (C.c_uint64 * 4) * 4),
+                ("q_arith", C.c_void_p), ("q_range", C.c_void_p), ("q_logic", C.c_void_p),
+                ("q_fixed_group_add", C.c_void_p), ("q_variable_group_add", C.c_void_p),
+                ("range_sep", C.c_uint64 * 4), ("logic_sep", C.c_uint64 * 4), ("fixed_sep", C.c_uint64 * 4),
+                ("var_sep", C.c_uint64 * 4)]
 
 
 class PlonkProof(C.Structure):
     """``pm_plonk_proof``"""
-    _fields_ = [("commitments", (C.c_uint64 * 12) * 11), ("evaluations", (C.c_uint64 * 4) * 10),
-                ("challenges", (C.c_uint64 * 4) * 6)]
+    _fields_ = [("commitments", (C.c_uint64 * 12) * 11), ("evaluations", (C.c_uint64 * 4) * 17),
+                ("challenges", (C.c_uint64 * 4) * 10)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint32)
+VK_POINTS = (C.c_uint64 * 12) * 15
+PLONK_SELECTORS, PLONK_PROOF_BYTES, PLONK_BIND_PUBLIC_INPUTS = 11, 1040, 1
+COMM_ID_BYTES, COMM_MAX_POINTS = 128, 16
 LINCOMB_MAX = 16
 
 # name -> (restype, argtypes); must list every function the header declares
@@ -84,10 +91,23 @@ SIGNATURES = {
     "pm_plonk_preprocess": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(C.c_int64), C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "pm_plonk_key_free": (None, [C.c_void_p, C.c_void_p]),
-    "pm_plonk_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p,
+    "pm_plonk_key_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p]),
+    "pm_plonk_key_commit_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                              C.c_char_p, C.c_void_p]),
+    "pm_plonk_verifier_key": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pm_plonk_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, u64p, u64p, C.c_size_t, C.c_uint32,
                                  C.POINTER(PlonkProof)]),
-    "pm_plonk_prove_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                         C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(PlonkProof)]),
+    "pm_plonk_prove_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, u64p, u64p,
+                                         C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(PlonkProof)]),
+    "pm_plonk_proof_to_bytes": (C.c_int, [C.POINTER(PlonkProof), C.POINTER(C.c_uint8)]),
+    "pm_fr_poly_evaluate_many_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_size_t, u64p, u64p,
+                                               C.c_void_p]),
+    "pm_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "pm_comm_init": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "pm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pm_g1_allgather_fold": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
+    "pm_test_fold_gathered": (C.c_int, [u64p, C.c_int, C.c_uint32, u64p]),
     "pm_keccak_f1600": (None, [C.c_char_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
@@ -104,6 +124,8 @@ PM_ERR_OOM = -3
 PM_ERR_HIP = -4
 PM_ERR_NO_DEVICE = -5
 PM_ERR_LENGTH = -6
+PM_ERR_EXCHANGE = -7
+PM_ERR_BUSY = -8
 
 NTT_INVERSE = 1
 NTT_COSET = 2

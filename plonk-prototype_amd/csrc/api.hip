@@ -121,6 +121,7 @@ extern "C" int pm_init(int device_id, pm_ctx** out) {
 
 extern "C" void pm_shutdown(pm_ctx* ctx) {
   if (!ctx) return;
+  (void)pm_comm_destroy(ctx);
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
   for (int d = 0; d < 2; ++d) {

@@ -1,0 +1,164 @@
+// The one exchange step of the hot path, inside the library (SURVEY.md section 8b "RCCL comm over the
+// listed GPUs", section 8e): one process per GPU, every rank holds a pm_ctx, the MSM is sharded by points
+// and the ranks exchange k partial G1 points -- ncclAllGather of a fixed 2312-byte message per rank over
+// RCCL / xGMI (RCCL has no reduction under the group law), then the same fold on every rank.  Used by
+// pm_plonk_prove_sharded / pm_plonk_key_commit_sharded when no exchange callback is given, and directly
+// through pm_g1_allgather_fold.  RCCL is bound at run time (dlopen of librccl.so.1 -- the copy a host
+// runtime such as PyTorch-ROCm already loaded, or the one in /opt/rocm/lib), so the library itself loads
+// on machines without it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "context.h"
+
+namespace pm {
+
+// the handful of RCCL entry points used (rccl.h: ncclResult_t = int, ncclComm_t = opaque pointer)
+struct ncclUniqueIdRaw {
+  char internal[PM_COMM_ID_BYTES];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(ncclUniqueIdRaw*) = nullptr;
+  int (*CommInitRank)(void**, int, ncclUniqueIdRaw, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int /* ncclDataType_t */, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
+};
+static Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  });
+  return r;
+}
+static const int kNcclUint64 = 5;   // ncclUint64 (nccl.h / rccl.h: int8 0, uint8 1, int32 2, uint32 3, int64 4, uint64 5)
+
+// message of one rank: [count | PM_COMM_MAX_POINTS x 18 limbs]; count = 0 is the abort marker of a rank
+// whose local work failed (it still enters the collective, so no peer blocks)
+static constexpr size_t MSG_WORDS = 1 + 18 * (size_t)PM_COMM_MAX_POINTS;
+
+// Fold what the ranks sent: out[j] = sum over ranks of point j.  -> PM_OK, or PM_ERR_EXCHANGE when a rank
+// sent the abort marker or the counts disagree.
+int fold_gathered(const uint64_t* msgs, int world, uint32_t k_local, uint64_t* out_xyz) {
+  for (int r = 0; r < world; ++r)
+    if (msgs[r * MSG_WORDS] == 0 || msgs[r * MSG_WORDS] != k_local) return PM_ERR_EXCHANGE;
+  std::vector<uint64_t> parts((size_t)world * 18);
+  for (uint32_t j = 0; j < k_local; ++j) {
+    for (int r = 0; r < world; ++r) memcpy(&parts[(size_t)r * 18], msgs + r * MSG_WORDS + 1 + 18 * (size_t)j, 144);
+    int rc = pm_g1_fold(parts.data(), (size_t)world, out_xyz + 18 * (size_t)j);
+    if (rc) return rc;
+  }
+  return PM_OK;
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" int pm_comm_unique_id(uint8_t id[PM_COMM_ID_BYTES]) {
+  if (!id) return PM_ERR_BAD_ARG;
+  Rccl& r = rccl();
+  if (!r.ok()) return PM_ERR_EXCHANGE;
+  ncclUniqueIdRaw raw;
+  if (r.GetUniqueId(&raw) != 0) return PM_ERR_EXCHANGE;
+  memcpy(id, raw.internal, PM_COMM_ID_BYTES);
+  return PM_OK;
+}
+
+extern "C" int pm_comm_init(pm_ctx* ctx, const uint8_t id[PM_COMM_ID_BYTES], int rank, int world) {
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (ctx->comm) return set_err(ctx, PM_ERR_BAD_ARG, "the context already has a communicator");
+  Rccl& r = rccl();
+  if (!r.ok()) return set_err(ctx, PM_ERR_EXCHANGE, "librccl.so.1 could not be loaded");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueIdRaw raw;
+  memcpy(raw.internal, id, PM_COMM_ID_BYTES);
+  void* comm = nullptr;
+  const int nrc = r.CommInitRank(&comm, world, raw, rank);
+  if (nrc != 0) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclCommInitRank: ") + r.GetErrorString(nrc));
+  hipError_t e = hipMalloc(&ctx->comm_send, MSG_WORDS * 8);
+  if (e == hipSuccess) e = hipMalloc(&ctx->comm_recv, MSG_WORDS * 8 * (size_t)world);
+  if (e == hipSuccess) e = hipHostMalloc(&ctx->comm_host, MSG_WORDS * 8 * ((size_t)world + 1), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)r.CommDestroy(comm);
+    if (ctx->comm_send) (void)hipFree(ctx->comm_send);
+    if (ctx->comm_recv) (void)hipFree(ctx->comm_recv);
+    ctx->comm_send = ctx->comm_recv = nullptr;
+    return set_err(ctx, PM_ERR_OOM, "communicator buffers");
+  }
+  ctx->comm = comm;
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  return PM_OK;
+}
+
+extern "C" int pm_comm_destroy(pm_ctx* ctx) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->comm) return PM_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)rccl().CommDestroy(ctx->comm);
+  (void)hipFree(ctx->comm_send);
+  (void)hipFree(ctx->comm_recv);
+  (void)hipHostFree(ctx->comm_host);
+  ctx->comm = ctx->comm_send = ctx->comm_recv = ctx->comm_host = nullptr;
+  ctx->comm_world = 1;
+  ctx->comm_rank = 0;
+  return PM_OK;
+}
+
+extern "C" int pm_comm_info(const pm_ctx* ctx, int* rank, int* world) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  if (rank) *rank = ctx->comm ? ctx->comm_rank : 0;
+  if (world) *world = ctx->comm ? ctx->comm_world : 1;
+  return PM_OK;
+}
+
+// k = 0: this rank gave up (abort marker).  Returns PM_ERR_EXCHANGE on every rank if any rank did.
+extern "C" int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k) {
+  if (!ctx || (k && !xyz) || k > PM_COMM_MAX_POINTS) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->comm) return set_err(ctx, PM_ERR_EXCHANGE, "no communicator: pm_comm_init first");
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  Rccl& r = rccl();
+  const int world = ctx->comm_world;
+  uint64_t* h_send = (uint64_t*)ctx->comm_host;
+  uint64_t* h_recv = h_send + MSG_WORDS;
+  memset(h_send, 0, MSG_WORDS * 8);
+  h_send[0] = k;
+  if (k) memcpy(h_send + 1, xyz, 144 * (size_t)k);
+  hipStream_t st = ctx->stream;
+  PM_HIP(ctx, hipMemcpyAsync(ctx->comm_send, h_send, MSG_WORDS * 8, hipMemcpyHostToDevice, st));
+  const int nrc = r.AllGather(ctx->comm_send, ctx->comm_recv, MSG_WORDS, kNcclUint64, ctx->comm, st);
+  if (nrc != 0) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclAllGather: ") + r.GetErrorString(nrc));
+  PM_HIP(ctx, hipMemcpyAsync(h_recv, ctx->comm_recv, MSG_WORDS * 8 * (size_t)world, hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipStreamSynchronize(st));
+  if (k == 0) return set_err(ctx, PM_ERR_EXCHANGE, "this rank aborted the exchange");
+  const int rc = fold_gathered(h_recv, world, k, xyz);
+  if (rc == PM_ERR_EXCHANGE) return set_err(ctx, rc, "a peer rank aborted the exchange (or sent a different count)");
+  return rc;
+}
+
+// Test hook: the fold of pm_g1_allgather_fold on messages given by the caller (world x 289 words), so the
+// packing, the abort marker and the count check can be exercised without several GPUs.
+extern "C" int pm_test_fold_gathered(const uint64_t* msgs, int world, uint32_t k, uint64_t* out_xyz) {
+  if (!msgs || !out_xyz || world < 1 || k == 0 || k > PM_COMM_MAX_POINTS) return PM_ERR_BAD_ARG;
+  return fold_gathered(msgs, world, k, out_xyz);
+}

@@ -61,6 +61,10 @@ struct pm_ctx {
   pm::DeviceBuffer poly_tab;                            // power tables of pm_fr_poly_ruffini_dev
   void* msm_host_pinned = nullptr;
   size_t msm_host_pinned_bytes = 0;
+  // multi-GPU exchange (comm.hip): RCCL communicator of this rank, device and pinned staging buffers
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  void *comm_send = nullptr, *comm_recv = nullptr, *comm_host = nullptr;
   // opt-in per-kernel timing (hipEvents on the launch stream; read by bench.py)
   bool profile = false;
   std::string profile_only;      // when set, only scopes with exactly this name record events

@@ -5,8 +5,11 @@
 //   pm_plonk_perm_terms_dev  numerator and denominator of the permutation grand product
 //   pm_plonk_quotient_dev    quotient numerator / Z_H on the 4n coset
 // Restates dusk_plonk::proof_system::{permutation, quotient_poly, linearisation_poly} of
-// dusk-plonk 0.8.2 (ref:Cargo.toml:19; not in the reference tree) for the arithmetic and
-// permutation identities; range / logic / curve-addition widgets are not built.
+// dusk-plonk 0.8.2 (ref:Cargo.toml:19; not in the reference tree): the arithmetic identity (times
+// q_arith), the permutation identities, and the four widgets behind the gates the reference's gadgets
+// emit -- range (ref:src/zk/gadgets.rs:88-91), logic / boolean (:211), fixed-base scalar
+// multiplication (:34,37; ref:src/zk/circuits.rs:64) and variable-base curve addition (:40).  The
+// formulas are restated from the published dusk-plonk 0.8 design (parity unpinned).
 //
 // Scaling bookkeeping (poly_common.cuh): memory holds ABI form (x 2^256); a product of forms 2^a and
 // 2^b is of form 2^(a+b-261).  Wires are moved to device form (2^261) once per point, challenges are
@@ -107,12 +110,39 @@ struct QuotPtrs {
   const u32x4* w[4];
   const u32x4* z;
   const u32x4 *q_m, *q_l, *q_r, *q_o, *q_4, *q_c, *pi;
+  const u32x4* q_arith;                      // nullptr = the constant 1
+  const u32x4 *q_range, *q_logic, *q_fixed, *q_var;   // nullptr = identically zero: the widget is skipped
   const u32x4* s[4];
   const u32x4* l1;
   const u32x4* x;
   u32x4* out;
 };
-__global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const RoundConsts kc, size_t n4) {
+// Everything the widgets multiply by, in device form (x 2^261)
+struct WidgetConsts {
+  u32 c1[9], c2[9], c3[9], c4[9], c9[9], c18[9], c81[9], c83[9], edwards_d[9];
+  u32 range_sep[9], range_k[3][9];   // separation challenge s and kappa = s^2, kappa^2, kappa^3
+  u32 logic_sep[9], logic_k[4][9];
+  u32 fixed_sep[9], fixed_k[3][9];
+  u32 var_sep[9], var_k[2][9];
+};
+
+// Widget arithmetic: every value in device form with normalised limbs and value < 1.02 r, closed
+// under these three (fe_mul: < x y / 2^261 + r; the weak reduction after + and - brings the value
+// back below r + r / 2^16).  Slower than the hand-scheduled lazy sums of the arithmetic identity, but
+// the widget rows are a small part of real circuits and the kernel stays VALU-bound either way.
+PM_DEV Fr wadd(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_add<FrP>(a, b)); }
+PM_DEV Fr wsub(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_sub<FrP, 2, 1>(a, b)); }
+PM_DEV Fr wmul(const Fr& a, const Fr& b) { return fe_mul<FrP>(a, b); }
+// f (f - 1)(f - 2)(f - 3): zero exactly on the quads 0..3
+PM_DEV Fr wdelta(const Fr& f, const WidgetConsts& c) {
+  Fr r = wmul(f, wsub(f, fr_limbs(c.c1)));
+  r = wmul(r, wsub(f, fr_limbs(c.c2)));
+  return wmul(r, wsub(f, fr_limbs(c.c3)));
+}
+
+template <bool WIDGETS>
+__global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const RoundConsts kc, const WidgetConsts wc,
+                                                       size_t n4) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;   // a multiple of 4: i mod 4 is fixed per thread
   const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 r4 = (u32)(t0 & 3);
@@ -126,13 +156,78 @@ __global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const R
     Fr w[4], f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = to_dev(ld_canon(p.w[j], i));
-    // arithmetic identity, ABI form: five (1, <2) products and two canonical loads -> (7, <12)
+    // arithmetic identity, ABI form: five (1, <2) products and one canonical load -> (6, <11)
     Fr g = fe_mul<FrP>(ld_canon(p.q_m, i), fe_mul<FrP>(w[0], w[1]));
     g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_l, i), w[0]));
     g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_r, i), w[1]));
     g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_o, i), w[2]));
     g = fe_add<FrP>(g, fe_mul<FrP>(ld_canon(p.q_4, i), w[3]));
-    g = fe_norm<FrP>(fe_add<FrP>(g, fe_add<FrP>(ld_canon(p.q_c, i), ld_canon(p.pi, i))));   // limbs back to (1)
+    g = fe_add<FrP>(g, ld_canon(p.q_c, i));
+    if (p.q_arith) g = fe_mul<FrP>(fe_norm<FrP>(g), to_dev(ld_canon(p.q_arith, i)));   // ABI x device -> ABI (1, <2)
+    if (WIDGETS) {
+      // the rows' other gate kinds; "next" = the same polynomial at w X = index + 4 on the 4n coset
+      const Fr a = w[0], b = w[1], c = w[2], d = w[3];
+      const Fr an = to_dev(ld_canon(p.w[0], inext)), bn = to_dev(ld_canon(p.w[1], inext)),
+               dn = to_dev(ld_canon(p.w[3], inext));
+      const Fr c4 = fr_limbs(wc.c4);
+      Fr wsum = fe_zero<FrP>();
+      if (p.q_range) {
+        Fr t = wdelta(wsub(c, wmul(d, c4)), wc);
+        t = wadd(t, wmul(wdelta(wsub(b, wmul(c, c4)), wc), fr_limbs(wc.range_k[0])));
+        t = wadd(t, wmul(wdelta(wsub(a, wmul(b, c4)), wc), fr_limbs(wc.range_k[1])));
+        t = wadd(t, wmul(wdelta(wsub(dn, wmul(a, c4)), wc), fr_limbs(wc.range_k[2])));
+        t = wmul(t, fr_limbs(wc.range_sep));
+        wsum = wadd(wsum, wmul(to_dev(ld_canon(p.q_range, i)), t));
+      }
+      if (p.q_logic) {
+        const Fr qa = wsub(an, wmul(a, c4)), qb = wsub(bn, wmul(b, c4)), qd = wsub(dn, wmul(d, c4));
+        const Fr qc = to_dev(ld_canon(p.q_c, i));
+        Fr t = wdelta(qa, wc);
+        t = wadd(t, wmul(wdelta(qb, wc), fr_limbs(wc.logic_k[0])));
+        t = wadd(t, wmul(wdelta(qd, wc), fr_limbs(wc.logic_k[1])));
+        t = wadd(t, wmul(wsub(c, wmul(qa, qb)), fr_limbs(wc.logic_k[2])));
+        // delta_xor_and(qa, qb, w = c, qd, q_c)
+        const Fr s = wadd(qa, qb);
+        Fr in = wadd(wsub(wmul(c, c4), wmul(s, fr_limbs(wc.c18))), fr_limbs(wc.c81));            // 4w - 18(a+b) + 81
+        in = wadd(wmul(c, in), wmul(wadd(wmul(qa, qa), wmul(qb, qb)), fr_limbs(wc.c18)));        // w(..) + 18(a^2+b^2)
+        in = wadd(wsub(in, wmul(s, fr_limbs(wc.c81))), fr_limbs(wc.c83));                        // - 81(a+b) + 83
+        const Fr ff = wmul(c, in);
+        const Fr e = wsub(wmul(wadd(s, qd), fr_limbs(wc.c3)), wadd(ff, ff));                    // 3(a+b+c) - 2f
+        const Fr bb = wmul(qc, wsub(wmul(qd, fr_limbs(wc.c9)), wmul(s, fr_limbs(wc.c3))));      // q_c (9c - 3(a+b))
+        t = wadd(t, wmul(wadd(bb, e), fr_limbs(wc.logic_k[3])));
+        t = wmul(t, fr_limbs(wc.logic_sep));
+        wsum = wadd(wsum, wmul(to_dev(ld_canon(p.q_logic, i)), t));
+      }
+      if (p.q_fixed) {
+        const Fr xb = to_dev(ld_canon(p.q_l, i)), yb = to_dev(ld_canon(p.q_r, i)), xyb = to_dev(ld_canon(p.q_c, i));
+        const Fr one = fr_limbs(wc.c1);
+        const Fr bit = wsub(dn, wadd(d, d));
+        Fr t = wmul(wmul(bit, wsub(bit, one)), wadd(bit, one));                                 // bit (bit-1)(bit+1)
+        const Fr ya = wadd(wmul(wmul(bit, bit), wsub(yb, one)), one);
+        const Fr xa = wmul(xb, bit);
+        t = wadd(t, wmul(wsub(wmul(bit, xyb), c), fr_limbs(wc.fixed_k[0])));
+        const Fr dxy = wmul(wmul(wmul(c, a), b), fr_limbs(wc.edwards_d));
+        const Fr xacc = wsub(wadd(an, wmul(an, dxy)), wadd(wmul(a, ya), wmul(b, xa)));
+        const Fr yacc = wsub(wsub(bn, wmul(bn, dxy)), wadd(wmul(b, ya), wmul(a, xa)));
+        t = wadd(t, wmul(xacc, fr_limbs(wc.fixed_k[1])));
+        t = wadd(t, wmul(yacc, fr_limbs(wc.fixed_k[2])));
+        t = wmul(t, fr_limbs(wc.fixed_sep));
+        wsum = wadd(wsum, wmul(to_dev(ld_canon(p.q_fixed, i)), t));
+      }
+      if (p.q_var) {
+        const Fr y1x2 = wmul(b, c), y1y2 = wmul(b, d), x1x2 = wmul(a, c);
+        Fr t = wsub(wmul(a, d), dn);                                                             // x1 y2 - x1y2
+        const Fr dd = wmul(wmul(dn, y1x2), fr_limbs(wc.edwards_d));
+        const Fr x3 = wsub(wadd(dn, y1x2), wadd(an, wmul(an, dd)));
+        const Fr y3 = wsub(wadd(y1y2, x1x2), wsub(bn, wmul(bn, dd)));
+        t = wadd(t, wmul(x3, fr_limbs(wc.var_k[0])));
+        t = wadd(t, wmul(y3, fr_limbs(wc.var_k[1])));
+        t = wmul(t, fr_limbs(wc.var_sep));
+        wsum = wadd(wsum, wmul(to_dev(ld_canon(p.q_var, i)), t));
+      }
+      g = fe_add<FrP>(g, wmul(wsum, fr_limbs(kc.one_abi)));                                      // device x 2^256 -> ABI
+    }
+    g = fe_norm<FrP>(fe_add<FrP>(g, ld_canon(p.pi, i)));   // limbs back to (1)
     // permutation identity
     const Fr x = ld_canon(p.x, i);
     const Fr z = ld_canon(p.z, i);
@@ -147,7 +242,7 @@ __global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const R
     // (z - 1) l1 alpha^2:  z - 1 + 2r is (4, <3); product with ABI l1 is 2^251, alpha2 restores 2^256
     const Fr zm1 = fe_sub<FrP, 2, 1>(z, fr_limbs(kc.one_abi));
     g = fe_add<FrP>(g, fe_mul<FrP>(fe_mul<FrP>(zm1, ld_canon(p.l1, i)), fr_limbs(kc.alpha2)));
-    // g: value < 16 r, limbs < 3 * 2^29 + 8
+    // g: value < 18 r, limbs < 3 * 2^29 + 16
     st_canon(p.out, i, fe_mul<FrP>(g, zhi));
   }
 }
@@ -270,6 +365,11 @@ extern "C" int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* 
   p.q_o = (const u32x4*)args->q_o;
   p.q_4 = (const u32x4*)args->q_4;
   p.q_c = (const u32x4*)args->q_c;
+  p.q_arith = (const u32x4*)args->q_arith;
+  p.q_range = (const u32x4*)args->q_range;
+  p.q_logic = (const u32x4*)args->q_logic;
+  p.q_fixed = (const u32x4*)args->q_fixed_group_add;
+  p.q_var = (const u32x4*)args->q_variable_group_add;
   p.pi = (const u32x4*)args->pi;
   p.l1 = (const u32x4*)args->l1;
   p.x = (const u32x4*)args->x;
@@ -280,10 +380,38 @@ extern "C" int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* 
     if (!q) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
   RoundConsts kc;
   fill_round_consts(kc, load_fr(args->alpha), load_fr(args->beta), load_fr(args->gamma), args->k, args->zh_inv);
+  const bool widgets = p.q_range || p.q_logic || p.q_fixed || p.q_var;
+  WidgetConsts wc;
+  memset(&wc, 0, sizeof wc);
+  if (widgets) {
+    const host::Field<4>& F = host::FR();
+    auto dev = [&](u32* dst, const HFr& v) { to_limbs29_shift(dst, v, 1); };
+    const struct { u32* dst; u64 v; } small[] = {{wc.c1, 1}, {wc.c2, 2}, {wc.c3, 3}, {wc.c4, 4}, {wc.c9, 9},
+                                                 {wc.c18, 18}, {wc.c81, 81}, {wc.c83, 83}};
+    for (const auto& c : small) dev(c.dst, host::from_u64(c.v, F));
+    // JubJub d = -(10240 / 10241)
+    dev(wc.edwards_d, host::sub(host::zero<4>(), host::mul(host::from_u64(10240, F), host::inv(host::from_u64(10241, F), F), F), F));
+    auto sep_powers = [&](const uint64_t sep[4], u32* s_out, u32 (*k_out)[9], int nk) {
+      const HFr s_ = load_fr(sep), kappa = host::mul(s_, s_, F);
+      dev(s_out, s_);
+      HFr kp = kappa;
+      for (int i = 0; i < nk; ++i) {
+        dev(k_out[i], kp);
+        kp = host::mul(kp, kappa, F);
+      }
+    };
+    sep_powers(args->range_sep, wc.range_sep, wc.range_k, 3);
+    sep_powers(args->logic_sep, wc.logic_sep, wc.logic_k, 4);
+    sep_powers(args->fixed_sep, wc.fixed_sep, wc.fixed_k, 3);
+    sep_powers(args->var_sep, wc.var_sep, wc.var_k, 2);
+  }
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   ProfScope prof(ctx, st, "plonk_quotient");
-  hipLaunchKernelGGL(quotient_kernel, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, 4 * n);
+  if (widgets)
+    hipLaunchKernelGGL(quotient_kernel<true>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n);
+  else
+    hipLaunchKernelGGL(quotient_kernel<false>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n);
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
 }

@@ -63,11 +63,16 @@ PM_DEV Fr block_sum_256(Fr v, u32* sh /* 256 * 9 words */) {
   return v;
 }
 // partial[b] = x^(b SEG) * sum_{i in segment b} c_i x^(i - b SEG),  SEG = 256 L, strided Horner
-__global__ void __launch_bounds__(256) poly_eval_kernel(const u32x4* coeffs, size_t n, u32 L, const EvalConsts kc,
+struct EvalPolys {
+  const u32x4* p[PM_LINCOMB_MAX];   // blockIdx.y selects the polynomial
+};
+__global__ void __launch_bounds__(256) poly_eval_kernel(const EvalPolys polys, size_t n, u32 L, const EvalConsts kc,
                                                          const u32x4* xpow /* x^t, t < 256 */,
-                                                         const u32x4* xblk /* x^(b SEG) */, u32x4* partial) {
+                                                         const u32x4* xblk /* x^(b SEG) */, u32x4* partial_all) {
   __shared__ u32 sh[256 * 9];
   const u32 t = threadIdx.x, b = blockIdx.x;
+  const u32x4* coeffs = polys.p[blockIdx.y];
+  u32x4* partial = partial_all + 3 * (size_t)blockIdx.y * gridDim.x;
   const size_t base = (size_t)b * 256 * L;
   const Fr xrow = fr_limbs(kc.xrow);
   Fr acc = fe_zero<FrP>();
@@ -83,13 +88,14 @@ __global__ void __launch_bounds__(256) poly_eval_kernel(const u32x4* coeffs, siz
     st_tw(partial, b, acc);
   }
 }
-__global__ void __launch_bounds__(256) poly_eval_final_kernel(const u32x4* partial, u32 count, u32x4* out) {
+__global__ void __launch_bounds__(256) poly_eval_final_kernel(const u32x4* partial_all, u32 count, u32x4* out) {
   __shared__ u32 sh[256 * 9];
   const u32 t = threadIdx.x;
+  const u32x4* partial = partial_all + 3 * (size_t)blockIdx.x * count;
   Fr acc = fe_zero<FrP>();
   for (u32 i = t; i < count; i += 256) acc = fe_reduce_weak<FrP>(fe_add<FrP>(acc, ld_tw(partial, i)));
   acc = block_sum_256(acc, sh);
-  if (t == 0) st_canon(out, 0, acc);
+  if (t == 0) st_canon(out, blockIdx.x, acc);
 }
 
 // ------------------------------------------------------------------ Ruffini
@@ -445,17 +451,27 @@ extern "C" int pm_fr_vec_op_dev(pm_ctx* ctx, int op, const void* d_a, const void
   return PM_OK;
 }
 
-extern "C" int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t point[4],
-                                       uint64_t out[4], void* hip_stream) {
+extern "C" int pm_fr_poly_evaluate_many_dev(pm_ctx* ctx, uint32_t k, const void* const* d_polys, size_t n,
+                                            const uint64_t point[4], uint64_t* out, void* hip_stream) {
   if (!ctx || !point || !out) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (k == 0) return PM_OK;
+  if (k > PM_LINCOMB_MAX) return set_err(ctx, PM_ERR_BAD_ARG, "k must be in 1..PM_LINCOMB_MAX");
   if (n == 0) {
-    memset(out, 0, 32);
+    memset(out, 0, 32 * (size_t)k);
     return PM_OK;
   }
-  if (!d_coeffs) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+  if (!d_polys) return set_err(ctx, PM_ERR_BAD_ARG, "null pointer");
+  EvalPolys polys;
+  memset(&polys, 0, sizeof polys);
+  for (uint32_t j = 0; j < k; ++j) {
+    if (!d_polys[j]) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+    polys.p[j] = (const u32x4*)d_polys[j];
+  }
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  int rc = order_on(ctx, ctx->ord_poly, st);
+  if (rc) return rc;
   const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
   const size_t seg = (size_t)256 * L;
   const u32 nblocks = (u32)((n + seg - 1) / seg);
@@ -466,12 +482,12 @@ extern "C" int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t
   to_limbs29(kc.xrow, hfr_pow_u64(x, 256));
   to_limbs29(kc.xseg, hfr_pow_u64(x, seg));
   to_limbs29(kc.one, host::one(host::FR()));
-  int rc = ensure_buffer(ctx, ctx->poly_ws, (size_t)(256 + 2 * (size_t)nblocks) * 48 + 64);
+  rc = ensure_buffer(ctx, ctx->poly_ws, (size_t)(256 + (1 + (size_t)k) * nblocks) * 48 + 32 * (size_t)k + 64);
   if (rc) return rc;
   u32x4* xpow = (u32x4*)ctx->poly_ws.ptr;
   u32x4* xblk = xpow + 3 * 256;
   u32x4* partial = xblk + 3 * (size_t)nblocks;
-  u32x4* d_out = partial + 3 * (size_t)nblocks;
+  u32x4* d_out = partial + 3 * (size_t)nblocks * k;
   {
     NttConsts c;
     memset(&c, 0, sizeof c);
@@ -482,14 +498,22 @@ extern "C" int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t
   }
   {
     ProfScope prof(ctx, st, "fr_poly_evaluate");
-    hipLaunchKernelGGL(poly_eval_kernel, dim3(nblocks), dim3(256), 0, st, (const u32x4*)d_coeffs, n, L, kc,
-                       (const u32x4*)xpow, (const u32x4*)xblk, partial);
-    hipLaunchKernelGGL(poly_eval_final_kernel, dim3(1), dim3(256), 0, st, (const u32x4*)partial, nblocks, d_out);
+    hipLaunchKernelGGL(poly_eval_kernel, dim3(nblocks, k), dim3(256), 0, st, polys, n, L, kc, (const u32x4*)xpow,
+                       (const u32x4*)xblk, partial);
+    hipLaunchKernelGGL(poly_eval_final_kernel, dim3(k), dim3(256), 0, st, (const u32x4*)partial, nblocks, d_out);
   }
   PM_HIP(ctx, hipGetLastError());
-  PM_HIP(ctx, hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipMemcpyAsync(out, d_out, 32 * (size_t)k, hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
   return PM_OK;
+}
+
+extern "C" int pm_fr_poly_evaluate_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t point[4],
+                                       uint64_t out[4], void* hip_stream) {
+  if (!ctx || !point || !out) return PM_ERR_BAD_ARG;
+  if (n && !d_coeffs) return PM_ERR_BAD_ARG;
+  const void* one[1] = {d_coeffs};
+  return pm_fr_poly_evaluate_many_dev(ctx, 1, one, n, point, out, hip_stream);
 }
 
 extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], void* d_out,
@@ -521,7 +545,8 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   // synchronisation from hipFree) inside a proving loop
   HFr zinv = host::inv(zz, F);
   const size_t tab_entries = 2 * ((size_t)n_lo + n_hi);
-  int rc = ensure_buffer(ctx, ctx->poly_tab, tab_entries * 48);
+  int rc = order_on(ctx, ctx->ord_poly, st);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_tab, tab_entries * 48);
   if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, m * 32 + (size_t)nblocks * 48 + 64);
   if (rc) return rc;
   u32x4* tab = (u32x4*)ctx->poly_tab.ptr;
@@ -559,7 +584,8 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   const size_t tile = (size_t)256 * PP_L;
   const u32 ntiles = (u32)((n + tile - 1) / tile);
-  int rc = ensure_buffer(ctx, ctx->poly_ws, (n + ntiles) * 48 + 64);
+  int rc = order_on(ctx, ctx->ord_poly, st);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, (n + ntiles) * 48 + 64);
   if (rc) return rc;
   u32x4* tmp = (u32x4*)ctx->poly_ws.ptr;
   u32x4* tile_tot = tmp + 3 * n;
@@ -589,7 +615,8 @@ extern "C" int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, voi
   const unsigned blocks = (unsigned)((want_threads + 255) / 256);
   const size_t T = (size_t)blocks * 256;
   const u32 L = (u32)((n + T - 1) / T);
-  int rc = ensure_buffer(ctx, ctx->poly_ws, n * 48);
+  int rc = order_on(ctx, ctx->ord_poly, st);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, n * 48);
   if (rc) return rc;
   ProfScope prof(ctx, st, "fr_batch_inverse");
   hipLaunchKernelGGL(batch_inverse_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)d_inout, n, L,

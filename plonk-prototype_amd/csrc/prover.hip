@@ -2,12 +2,15 @@
 // pm_plonk_prove), so that a Rust (or Go, or C) prover needs no host logic of its own between the
 // NTT and MSM kernels -- SURVEY.md section 8f rows N1 + N2 + N3, BASELINE.json configs[3].
 //
-// Restates dusk_plonk::proof_system::Prover::prove_with_preprocessed (dusk-plonk 0.8.2,
-// ref:Cargo.toml:19; not in the reference tree) for the arithmetic gate and the 4-wire permutation,
-// with a Merlin / STROBE-128 transcript (merlin is a dependency of dusk-plonk).  The same sequence
-// exists in Python (plonk-prototype_amd/prover.py); tests require the two to produce identical
-// proofs.  Everything here is sequencing and scalar arithmetic on a dozen field elements: the
-// vector work is done by the library's own entry points, called like any client would call them.
+// Restates dusk_plonk::proof_system::{Prover::preprocess, Prover::prove_with_preprocessed} (dusk-plonk
+// 0.8.2, ref:Cargo.toml:19; not in the reference tree) from the published design: 11 selector
+// polynomials (arithmetic + q_arith, range, logic, fixed-base, variable-base), the 4-wire
+// permutation, a Merlin / STROBE-128 transcript seeded with the verifier key, the 16-evaluation
+// Proof, aggregate opening witnesses.  These are the gate kinds the reference's own gadgets emit
+// (ref:src/zk/gadgets.rs:34,37,40,88-91,211; ref:src/zk/circuits.rs:64-70).  PARITY UNPINNED:
+// formulas and transcript labels are restated, not compared with upstream bytes.  Everything here is
+// sequencing and scalar arithmetic on a few dozen field elements: the vector work is done by the
+// library's own entry points, called like any client would call them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -16,7 +19,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/plonk_mi355x.h"
+#include "context.h"
 #include "host_field.h"
 
 namespace {
@@ -91,6 +94,10 @@ struct Strobe128 {
 struct Transcript {
   Strobe128 s;
   explicit Transcript(const std::string& label) : s("Merlin v1.0") { append("dom-sep", (const uint8_t*)label.data(), label.size()); }
+  static void scalar_bytes(uint8_t b[32], const HFr& v) {
+    const HFr c = fr_canonical(v);
+    for (int i = 0; i < 32; ++i) b[i] = (uint8_t)(c.l[i / 8] >> (8 * (i % 8)));
+  }
   void append(const char* label, const uint8_t* msg, size_t n) {
     s.meta_ad((const uint8_t*)label, strlen(label), false);
     uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
@@ -102,9 +109,13 @@ struct Transcript {
     for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(v >> (8 * i));
     append(label, b, 8);
   }
-  // 48-byte zcash compressed G1 (big-endian x; bit 7 compressed, bit 6 infinity, bit 5 = y > (p-1)/2)
   void append_commitment(const char* label, const u64 xy[12]) {
     uint8_t out[48];
+    g1_compress(out, xy);
+    append(label, out, 48);
+  }
+  // 48-byte zcash compressed G1 (big-endian x; bit 7 compressed, bit 6 infinity, bit 5 = y > (p-1)/2)
+  static void g1_compress(uint8_t out[48], const u64 xy[12]) {
     memset(out, 0, 48);
     bool any = false;
     for (int i = 0; i < 12; ++i) any = any || xy[i];
@@ -123,7 +134,6 @@ struct Transcript {
       HFp ny = pm::host::sub(pm::host::zero<6>(), y, pm::host::FP());   // canonical limbs: p - y
       if (pm::host::geq<6>(y.l, ny.l) && !pm::host::eq(y, ny)) out[0] |= 0x20;
     }
-    append(label, out, 48);
   }
   void append_scalar(const char* label, const HFr& v) {
     const HFr c = fr_canonical(v);
@@ -153,7 +163,68 @@ HFr get(const u64 src[4]) {
 }
 char* at(void* base, size_t elems) { return (char*)base + 32 * elems; }
 
-const char* SEL_NAMES[6] = {"q_m", "q_l", "q_r", "q_o", "q_4", "q_c"};
+// selector order of dusk's VerifierKey::seed_transcript (and of the ABI)
+enum { Q_M, Q_L, Q_R, Q_O, Q_C, Q_4, Q_ARITH, Q_RANGE, Q_LOGIC, Q_FIXED, Q_VAR, NSEL };
+const char* SEL_LABELS[NSEL] = {"q_m", "q_l", "q_r", "q_o", "q_c", "q_4", "q_arith", "q_range", "q_logic",
+                                "q_variable_group_add", "q_fixed_group_add"};   // (transcript order: variable before fixed)
+const int SEL_SEED_ORDER[NSEL] = {Q_M, Q_L, Q_R, Q_O, Q_C, Q_4, Q_ARITH, Q_RANGE, Q_LOGIC, Q_VAR, Q_FIXED};
+const char* SIGMA_LABELS[4] = {"left_sigma", "right_sigma", "out_sigma", "fourth_sigma"};
+
+// ---- the widgets' linearisation scalars: the same identities as plonk_rounds.hip's quotient kernel,
+// on the opening evaluations (widget::*::ProverKey::compute_linearisation)
+HFr small(u64 v) { return fr_u64(v); }
+HFr wdelta(const HFr& f) {
+  return fmul(fmul(fmul(f, fsub(f, small(1))), fsub(f, small(2))), fsub(f, small(3)));
+}
+HFr edwards_d() { return fneg(fmul(small(10240), finv(small(10241)))); }
+struct RowEvals {
+  HFr a, b, c, d, an, bn, dn, q_l, q_r, q_c;
+};
+HFr widget_range(const HFr& sep, const RowEvals& e) {
+  const HFr k = fmul(sep, sep), k2 = fmul(k, k), k3 = fmul(k2, k), four = small(4);
+  HFr t = wdelta(fsub(e.c, fmul(four, e.d)));
+  t = fadd(t, fmul(wdelta(fsub(e.b, fmul(four, e.c))), k));
+  t = fadd(t, fmul(wdelta(fsub(e.a, fmul(four, e.b))), k2));
+  t = fadd(t, fmul(wdelta(fsub(e.dn, fmul(four, e.a))), k3));
+  return fmul(t, sep);
+}
+HFr widget_logic(const HFr& sep, const RowEvals& e) {
+  const HFr k = fmul(sep, sep), k2 = fmul(k, k), k3 = fmul(k2, k), k4 = fmul(k2, k2), four = small(4);
+  const HFr qa = fsub(e.an, fmul(four, e.a)), qb = fsub(e.bn, fmul(four, e.b)), qd = fsub(e.dn, fmul(four, e.d));
+  const HFr s = fadd(qa, qb), w = e.c;
+  HFr in = fadd(fsub(fmul(four, w), fmul(small(18), s)), small(81));
+  in = fadd(fmul(w, in), fmul(small(18), fadd(fmul(qa, qa), fmul(qb, qb))));
+  in = fadd(fsub(in, fmul(small(81), s)), small(83));
+  const HFr f = fmul(w, in);
+  const HFr ee = fsub(fmul(small(3), fadd(s, qd)), fadd(f, f));
+  const HFr bb = fmul(e.q_c, fsub(fmul(small(9), qd), fmul(small(3), s)));
+  HFr t = wdelta(qa);
+  t = fadd(t, fmul(wdelta(qb), k));
+  t = fadd(t, fmul(wdelta(qd), k2));
+  t = fadd(t, fmul(fsub(w, fmul(qa, qb)), k3));
+  t = fadd(t, fmul(fadd(bb, ee), k4));
+  return fmul(t, sep);
+}
+HFr widget_fixed(const HFr& sep, const RowEvals& e) {
+  const HFr k = fmul(sep, sep), k2 = fmul(k, k), k3 = fmul(k2, k), one = fone();
+  const HFr bit = fsub(e.dn, fadd(e.d, e.d));
+  HFr t = fmul(fmul(bit, fsub(bit, one)), fadd(bit, one));
+  const HFr ya = fadd(fmul(fmul(bit, bit), fsub(e.q_r, one)), one), xa = fmul(e.q_l, bit);
+  t = fadd(t, fmul(fsub(fmul(bit, e.q_c), e.c), k));
+  const HFr dxy = fmul(fmul(fmul(e.c, e.a), e.b), edwards_d());
+  t = fadd(t, fmul(fsub(fadd(e.an, fmul(e.an, dxy)), fadd(fmul(e.a, ya), fmul(e.b, xa))), k2));
+  t = fadd(t, fmul(fsub(fsub(e.bn, fmul(e.bn, dxy)), fadd(fmul(e.b, ya), fmul(e.a, xa))), k3));
+  return fmul(t, sep);
+}
+HFr widget_var(const HFr& sep, const RowEvals& e) {
+  const HFr k = fmul(sep, sep), k2 = fmul(k, k);
+  const HFr y1x2 = fmul(e.b, e.c), y1y2 = fmul(e.b, e.d), x1x2 = fmul(e.a, e.c);
+  HFr t = fsub(fmul(e.a, e.d), e.dn);
+  const HFr dd = fmul(fmul(e.dn, y1x2), edwards_d());
+  t = fadd(t, fmul(fsub(fadd(e.dn, y1x2), fadd(e.an, fmul(e.an, dd))), k));
+  t = fadd(t, fmul(fsub(fadd(y1y2, x1x2), fsub(e.bn, fmul(e.bn, dd))), k2));
+  return fmul(t, sep);
+}
 }  // namespace
 
 struct pm_prover_key {
@@ -161,12 +232,34 @@ struct pm_prover_key {
   uint32_t log_n = 0;
   HFr omega, k[3], zh_inv[4];
   // device arrays (pm_dev_alloc)
-  void *roots = nullptr, *x4 = nullptr, *sel_coeffs = nullptr, *sel_coset = nullptr, *sigma_evals = nullptr,
+  void *roots = nullptr, *x4 = nullptr, *sel_coeffs = nullptr /* 11 n */, *sigma_evals = nullptr,
        *sigma_coeffs = nullptr, *sigma_coset = nullptr, *l1_coset = nullptr;
-  // per-proof workspace: coeffs [a b c d z pi] 6n | num n | den n | coset 24n | t 4n | r n | agg n | wit 2n | pi0 n
+  void* sel_coset[NSEL] = {};         // 4n each; nullptr where the quotient kernel does not read it
+  bool sel_zero[NSEL] = {};           // identically zero
+  bool arith_is_one = false;          // q_arith = 1 everywhere: the kernel skips the multiplication
+  // per-proof workspace: coeffs [a b c d z pi] 6n | num n | den n | coset 24n | t 4n | r n | agg n | wit 2n | pi n
   void *coeffs = nullptr, *num = nullptr, *den = nullptr, *coset = nullptr, *t = nullptr, *r = nullptr, *agg = nullptr,
-       *wit = nullptr, *pi_zero = nullptr;
+       *wit = nullptr, *pi_evals = nullptr;
+  // verifier key (commitments to the 11 selector and 4 sigma polynomials) and the transcript seeded with it
+  bool committed = false;
+  u64 vk[NSEL + 4][12] = {};
+  Transcript base{std::string("plonk")};
+  bool busy = false;                  // a proof is running on this key's workspace
+  hipStream_t side = nullptr;         // second stream: work that does not depend on the next challenge
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
 };
+
+// side stream <- everything submitted on the context's stream so far / the reverse
+static int pm_stream_fork(pm_ctx* ctx, hipStream_t side, hipEvent_t ev) {
+  PM_HIP(ctx, hipEventRecord(ev, ctx->stream));
+  PM_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
+  return PM_OK;
+}
+static int pm_stream_join(pm_ctx* ctx, hipStream_t side, hipEvent_t ev) {
+  PM_HIP(ctx, hipEventRecord(ev, side));
+  PM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+  return PM_OK;
+}
 
 #define PK_TRY(call)            \
   do {                          \
@@ -176,14 +269,23 @@ struct pm_prover_key {
 
 extern "C" void pm_plonk_key_free(pm_ctx* ctx, pm_prover_key* pk) {
   if (!pk) return;
-  for (void* p : {pk->roots, pk->x4, pk->sel_coeffs, pk->sel_coset, pk->sigma_evals, pk->sigma_coeffs, pk->sigma_coset,
-                  pk->l1_coset, pk->coeffs, pk->num, pk->den, pk->coset, pk->t, pk->r, pk->agg, pk->wit, pk->pi_zero})
+  if (ctx) (void)pm_sync(ctx);
+  if (pk->side) {
+    (void)hipStreamSynchronize(pk->side);
+    (void)hipStreamDestroy(pk->side);
+  }
+  if (pk->ev_main) (void)hipEventDestroy(pk->ev_main);
+  if (pk->ev_side) (void)hipEventDestroy(pk->ev_side);
+  for (void* p : {pk->roots, pk->x4, pk->sel_coeffs, pk->sigma_evals, pk->sigma_coeffs, pk->sigma_coset,
+                  pk->l1_coset, pk->coeffs, pk->num, pk->den, pk->coset, pk->t, pk->r, pk->agg, pk->wit, pk->pi_evals})
+    if (p && ctx) (void)pm_dev_free(ctx, p);
+  for (void* p : pk->sel_coset)
     if (p && ctx) (void)pm_dev_free(ctx, p);
   delete pk;
 }
 
-extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[6], const int64_t* sigma_index, size_t n,
-                                   pm_prover_key** out) {
+extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[PM_PLONK_SELECTORS],
+                                   const int64_t* sigma_index, size_t n, pm_prover_key** out) {
   if (!ctx || !selectors || !sigma_index || !out) return PM_ERR_BAD_ARG;
   *out = nullptr;
   if (n < 4 || (n & (n - 1))) return PM_ERR_LENGTH;
@@ -203,23 +305,45 @@ extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[
   pk->k[0] = fr_u64(7);
   pk->k[1] = fr_u64(13);
   pk->k[2] = fr_u64(17);
+  // which selector polynomials are trivial: the quotient kernel skips what it can
+  pk->arith_is_one = selectors[Q_ARITH] != nullptr;
+  for (int s = 0; s < NSEL; ++s) {
+    bool zero = true;
+    if (selectors[s]) {
+      for (size_t i = 0; i < 4 * n && zero; ++i) zero = selectors[s][i] == 0;
+    }
+    pk->sel_zero[s] = zero;
+  }
+  if (selectors[Q_ARITH])
+    for (size_t i = 0; i < n && pk->arith_is_one; ++i) pk->arith_is_one = memcmp(selectors[Q_ARITH] + 4 * i, one.l, 32) == 0;
   struct Alloc { void** p; size_t elems; };
-  const Alloc allocs[] = {{&pk->roots, n},         {&pk->x4, 4 * n},         {&pk->sel_coeffs, 6 * n}, {&pk->sel_coset, 24 * n},
-                          {&pk->sigma_evals, 4 * n}, {&pk->sigma_coeffs, 4 * n}, {&pk->sigma_coset, 16 * n}, {&pk->l1_coset, 4 * n},
-                          {&pk->coeffs, 6 * n},    {&pk->num, n},            {&pk->den, n},            {&pk->coset, 24 * n},
-                          {&pk->t, 4 * n},         {&pk->r, n},              {&pk->agg, n},            {&pk->wit, 2 * n},
-                          {&pk->pi_zero, n}};
+  std::vector<Alloc> allocs = {{&pk->roots, n},          {&pk->x4, 4 * n},           {&pk->sel_coeffs, (size_t)NSEL * n},
+                               {&pk->sigma_evals, 4 * n}, {&pk->sigma_coeffs, 4 * n}, {&pk->sigma_coset, 16 * n},
+                               {&pk->l1_coset, 4 * n},    {&pk->coeffs, 6 * n},       {&pk->num, n},
+                               {&pk->den, n},             {&pk->coset, 24 * n},       {&pk->t, 4 * n},
+                               {&pk->r, n},               {&pk->agg, n},              {&pk->wit, 2 * n},
+                               {&pk->pi_evals, n}};
+  for (int s = 0; s < NSEL; ++s) {
+    const bool need = s <= Q_4 || (s == Q_ARITH ? !pk->arith_is_one : !pk->sel_zero[s]);
+    if (need) allocs.push_back({&pk->sel_coset[s], 4 * n});
+  }
   for (const Alloc& a : allocs)
     if ((rc = pm_dev_alloc(ctx, a.elems * 32, a.p)) != PM_OK) break;
   void* tmp = nullptr;
   std::vector<u64> table, gathered;
   if (!rc) rc = pm_fr_powers_dev(ctx, pk->omega.l, one.l, n, pk->roots, nullptr);
   if (!rc) rc = pm_fr_powers_dev(ctx, omega4.l, g.l, 4 * n, pk->x4, nullptr);
-  // selectors: evaluations -> coefficients -> 4n coset
-  if (!rc) rc = pm_dev_alloc(ctx, 6 * n * 32, &tmp);
-  for (int s = 0; s < 6 && !rc; ++s) rc = pm_dev_upload(ctx, at(tmp, s * n), selectors[s], n * 32);
-  if (!rc) rc = pm_fr_ntt_dev(ctx, tmp, n, n, pk->sel_coeffs, n, lg, 6, PM_NTT_INVERSE, nullptr);
-  if (!rc) rc = pm_fr_ntt_dev(ctx, pk->sel_coeffs, n, n, pk->sel_coset, 4 * n, lg + 2, 6, PM_NTT_COSET, nullptr);
+  // selectors: evaluations -> coefficients -> 4n coset (only the coset forms the quotient kernel reads)
+  if (!rc) rc = pm_dev_alloc(ctx, (size_t)NSEL * n * 32, &tmp);
+  const HFr zero = pm::host::zero<4>();
+  for (int s = 0; s < NSEL && !rc; ++s) {
+    if (pk->sel_zero[s]) rc = pm_fr_powers_dev(ctx, zero.l, zero.l, n, at(tmp, s * n), nullptr);
+    else rc = pm_dev_upload(ctx, at(tmp, s * n), selectors[s], n * 32);
+  }
+  if (!rc) rc = pm_fr_ntt_dev(ctx, tmp, n, n, pk->sel_coeffs, n, lg, NSEL, PM_NTT_INVERSE, nullptr);
+  for (int s = 0; s < NSEL && !rc; ++s)
+    if (pk->sel_coset[s])
+      rc = pm_fr_ntt_dev(ctx, at(pk->sel_coeffs, s * n), n, n, pk->sel_coset[s], 4 * n, lg + 2, 1, PM_NTT_COSET, nullptr);
   // sigma_j(w^i) = k_j' w^i': gather from the table of the 4n points of the cosets k_j H
   if (!rc) {
     const HFr ks[4] = {one, pk->k[0], pk->k[1], pk->k[2]};
@@ -258,6 +382,9 @@ extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[
       p = fmul(p, i4);
     }
   }
+  if (!rc && hipStreamCreateWithFlags(&pk->side, hipStreamNonBlocking) != hipSuccess) rc = PM_ERR_HIP;
+  if (!rc && hipEventCreateWithFlags(&pk->ev_main, hipEventDisableTiming) != hipSuccess) rc = PM_ERR_HIP;
+  if (!rc && hipEventCreateWithFlags(&pk->ev_side, hipEventDisableTiming) != hipSuccess) rc = PM_ERR_HIP;
   if (rc) {
     pm_plonk_key_free(ctx, pk);
     return rc;
@@ -268,25 +395,35 @@ extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[
 
 // Commitments to `batch` coefficient vectors of n elements.  With the SRS split over ranks (shard.fn set)
 // this rank's bases cover coefficients [shard.lo, shard.lo + len(ck)): it computes the partial sums of its
-// slice and the exchange callback returns the sums over all ranks (all-gather + group-law fold).
+// slice and the exchange callback returns the sums over all ranks (all-gather + group-law fold).  A rank
+// whose local MSM fails still enters the exchange (with an abort marker) so that its peers do not block.
 struct Shard {
   size_t lo = 0;
-  pm_exchange_fn fn = nullptr;
+  bool on = false;             // the SRS is split: partial sums are exchanged
+  pm_exchange_fn fn = nullptr; // nullptr with on = true: the context's RCCL communicator (pm_g1_allgather_fold)
   void* user = nullptr;
 };
 static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const void* d, size_t n, size_t stride,
                         uint32_t batch, u64 (*out_xy)[12]) {
-  u64 xyz[4 * 18];
+  u64 xyz[16 * 18];
+  if (batch > 16) return PM_ERR_BAD_ARG;
   const size_t have = pm_g1_bases_len(ck);
   size_t cnt = n;
-  if (sh.fn) cnt = sh.lo < n ? std::min(have, n - sh.lo) : 0;
+  if (sh.on) cnt = sh.lo < n ? std::min(have, n - sh.lo) : 0;
+  int rc = PM_OK;
   if (cnt > 0) {
-    PK_TRY(pm_g1_msm_batch_dev(ctx, ck, 0, cnt, at((void*)d, sh.lo), stride, batch, PM_SCALAR_MONTGOMERY, xyz, nullptr));
+    rc = pm_g1_msm_batch_dev(ctx, ck, 0, cnt, at((void*)d, sh.lo), stride, batch, PM_SCALAR_MONTGOMERY, xyz, nullptr);
   } else {
     memset(xyz, 0, sizeof xyz);
     for (uint32_t b = 0; b < batch; ++b) memcpy(xyz + 18 * b + 6, pm::host::FP().one, 48);   // (0, 1, 0)
   }
-  if (sh.fn && sh.fn(sh.user, xyz, batch) != 0) return PM_ERR_BAD_ARG;
+  if (sh.on) {
+    // k = 0 tells the peers that this rank gave up: they get an error back and stop too
+    const uint32_t k = rc == PM_OK ? batch : 0;
+    const int xrc = sh.fn ? (sh.fn(sh.user, xyz, k) != 0 ? PM_ERR_EXCHANGE : PM_OK) : pm_g1_allgather_fold(ctx, xyz, k);
+    if (rc == PM_OK && xrc != PM_OK) rc = xrc;
+  }
+  if (rc) return rc;
   for (uint32_t b = 0; b < batch; ++b) {
     int ident = 0;
     PK_TRY(pm_g1_to_affine(xyz + 18 * b, out_xy[b], &ident));
@@ -294,42 +431,122 @@ static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const 
   return PM_OK;
 }
 
-static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
-                      const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out);
+static int key_commit_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard,
+                           const char* transcript_label, uint64_t (*vk_out)[12]) {
+  if (!ctx || !pk || !ck) return PM_ERR_BAD_ARG;
+  const size_t n = pk->n;
+  if (!shard.on && pm_g1_bases_len(ck) < n) return PM_ERR_LENGTH;
+  // the verifier key: commitments to the 11 selector and the 4 sigma polynomials
+  PK_TRY(commit_batch(ctx, ck, shard, pk->sel_coeffs, n, n, NSEL, &pk->vk[0]));
+  PK_TRY(commit_batch(ctx, ck, shard, pk->sigma_coeffs, n, n, 4, &pk->vk[NSEL]));
+  // Prover::preprocess: Transcript::new(label), VerifierKey::seed_transcript, circuit_domain_sep(n)
+  Transcript ts(transcript_label ? transcript_label : "plonk");
+  for (int i = 0; i < NSEL; ++i) ts.append_commitment(SEL_LABELS[i], pk->vk[SEL_SEED_ORDER[i]]);
+  for (int j = 0; j < 4; ++j) ts.append_commitment(SIGMA_LABELS[j], pk->vk[NSEL + j]);
+  ts.append("dom-sep", (const uint8_t*)"circuit_size", 12);
+  ts.append_u64("n", n);
+  pk->base = ts;
+  pk->committed = true;
+  if (vk_out) memcpy(vk_out, pk->vk, sizeof pk->vk);
+  return PM_OK;
+}
 
-extern "C" int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck_slice, size_t first_coefficient,
-                                      const void* d_witness, const void* d_public_inputs, const char* transcript_label,
-                                      pm_exchange_fn exchange, void* user, pm_plonk_proof* out) {
-  if (!exchange) return PM_ERR_BAD_ARG;
+extern "C" int pm_plonk_key_commit(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, const char* transcript_label,
+                                   uint64_t (*verifier_key_out)[12]) {
+  return key_commit_impl(ctx, key, commit_key, Shard(), transcript_label, verifier_key_out);
+}
+extern "C" int pm_plonk_key_commit_sharded(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key_slice,
+                                           size_t first_coefficient, pm_exchange_fn exchange, void* user,
+                                           const char* transcript_label, uint64_t (*verifier_key_out)[12]) {
   Shard sh;
+  sh.on = true;
   sh.lo = first_coefficient;
   sh.fn = exchange;
   sh.user = user;
-  return prove_impl(ctx, pk, ck_slice, sh, d_witness, d_public_inputs, transcript_label, out);
-}
-
-extern "C" int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const void* d_witness,
-                              const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out) {
-  return prove_impl(ctx, pk, ck, Shard(), d_witness, d_public_inputs, transcript_label, out);
+  return key_commit_impl(ctx, key, commit_key_slice, sh, transcript_label, verifier_key_out);
 }
 
 static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
-                      const void* d_public_inputs, const char* transcript_label, pm_plonk_proof* out) {
+                      const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
+                      pm_plonk_proof* out);
+
+extern "C" int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck_slice, size_t first_coefficient,
+                                      const void* d_witness, const uint64_t* pi_positions, const uint64_t* pi_values,
+                                      size_t n_pi, uint32_t flags, pm_exchange_fn exchange, void* user,
+                                      pm_plonk_proof* out) {
+  Shard sh;
+  sh.on = true;
+  sh.lo = first_coefficient;
+  sh.fn = exchange;
+  sh.user = user;
+  return prove_impl(ctx, pk, ck_slice, sh, d_witness, pi_positions, pi_values, n_pi, flags, out);
+}
+
+extern "C" int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const void* d_witness,
+                              const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
+                              pm_plonk_proof* out) {
+  return prove_impl(ctx, pk, ck, Shard(), d_witness, pi_positions, pi_values, n_pi, flags, out);
+}
+
+namespace {
+struct BusyGuard {   // one proof at a time per key: the key owns the per-proof workspace
+  pm_prover_key* pk;
+  bool ok;
+  explicit BusyGuard(pm_prover_key* k) : pk(k), ok(!k->busy) {
+    if (ok) pk->busy = true;
+  }
+  ~BusyGuard() {
+    if (ok) pk->busy = false;
+  }
+};
+}  // namespace
+
+static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
+                      const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
+                      pm_plonk_proof* out) {
   if (!ctx || !pk || !ck || !d_witness || !out) return PM_ERR_BAD_ARG;
+  if (n_pi && (!pi_positions || !pi_values)) return PM_ERR_BAD_ARG;
+  if (flags & ~PM_PLONK_BIND_PUBLIC_INPUTS) return PM_ERR_BAD_ARG;
+  if (!pk->committed) return PM_ERR_BAD_ARG;   // pm_plonk_key_commit first: the transcript starts from the verifier key
+  BusyGuard guard(pk);
+  if (!guard.ok) return PM_ERR_BUSY;
   const size_t n = pk->n;
   const uint32_t lg = pk->log_n;
-  if (!shard.fn && pm_g1_bases_len(ck) < n) return PM_ERR_LENGTH;
-  Transcript ts(transcript_label ? transcript_label : "plonk");
-  ts.append("dom-sep", (const uint8_t*)"circuit_size", 12);
-  ts.append_u64("n", n);
-  const HFr one = fone();
+  if (!shard.on && pm_g1_bases_len(ck) < n) return PM_ERR_LENGTH;
+  for (size_t i = 0; i < n_pi; ++i)
+    if (pi_positions[i] >= n) return PM_ERR_LENGTH;
+  Transcript ts = pk->base;
+  if (flags & PM_PLONK_BIND_PUBLIC_INPUTS) {
+    // not in dusk-plonk 0.8.2 (its transcript never sees the public inputs): binds the statement to the
+    // challenges so that it cannot be chosen after them
+    ts.append_u64("pi_len", n_pi);
+    for (size_t i = 0; i < n_pi; ++i) {
+      ts.append_u64("pi_pos", pi_positions[i]);
+      ts.append_scalar("pi", get(pi_values + 4 * i));
+    }
+  }
+  const HFr one = fone(), zero = pm::host::zero<4>();
   // ---- round 1 --------------------------------------------------------------------------------
   PK_TRY(pm_fr_ntt_dev(ctx, d_witness, n, n, pk->coeffs, n, lg, 4, PM_NTT_INVERSE, nullptr));
+  // work no challenge depends on goes to the side stream and runs under the MSMs of rounds 1 and 2:
+  // the public-input polynomial and the wire polynomials on the 4n coset (round 3 reads them)
+  hipStream_t side = pk->side;
+  void* pi_coeffs = at(pk->coeffs, 5 * n);
+  {
+    PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, n, pk->pi_evals, nullptr));
+    for (size_t i = 0; i < n_pi; ++i) PK_TRY(pm_dev_upload(ctx, at(pk->pi_evals, pi_positions[i]), pi_values + 4 * i, 32));
+    PK_TRY(pm_fr_ntt_dev(ctx, pk->pi_evals, n, n, pi_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
+    PK_TRY(pm_stream_fork(ctx, side, pk->ev_main));
+    PK_TRY(pm_fr_ntt_dev(ctx, pk->coeffs, n, n, pk->coset, 4 * n, lg + 2, 4, PM_NTT_COSET, side));
+    PK_TRY(pm_fr_ntt_dev(ctx, pi_coeffs, n, n, at(pk->coset, 4 * n * 5), 4 * n, lg + 2, 1, PM_NTT_COSET, side));
+  }
   PK_TRY(commit_batch(ctx, ck, shard, pk->coeffs, n, n, 4, &out->commitments[0]));
-  const char* wl[4] = {"w_a", "w_b", "w_c", "w_d"};
+  const char* wl[4] = {"w_l", "w_r", "w_o", "w_4"};
   for (int j = 0; j < 4; ++j) ts.append_commitment(wl[j], out->commitments[j]);
   // ---- round 2 --------------------------------------------------------------------------------
-  const HFr beta = ts.challenge_scalar("beta"), gamma = ts.challenge_scalar("gamma");
+  const HFr beta = ts.challenge_scalar("beta");
+  ts.append_scalar("beta", beta);
+  const HFr gamma = ts.challenge_scalar("gamma");
   pm_plonk_perm_args pa;
   memset(&pa, 0, sizeof pa);
   for (int j = 0; j < 4; ++j) {
@@ -350,15 +567,12 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   ts.append_commitment("z", out->commitments[4]);
   // ---- round 3 --------------------------------------------------------------------------------
   const HFr alpha = ts.challenge_scalar("alpha");
-  void* pi_coeffs = at(pk->coeffs, 5 * n);
-  const void* pi_ev = d_public_inputs;
-  if (!pi_ev) {
-    const HFr zero = pm::host::zero<4>();
-    PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, n, pk->pi_zero, nullptr));
-    pi_ev = pk->pi_zero;
-  }
-  PK_TRY(pm_fr_ntt_dev(ctx, pi_ev, n, n, pi_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
-  PK_TRY(pm_fr_ntt_dev(ctx, pk->coeffs, n, n, pk->coset, 4 * n, lg + 2, 6, PM_NTT_COSET, nullptr));
+  const HFr range_sep = ts.challenge_scalar("range separation challenge");
+  const HFr logic_sep = ts.challenge_scalar("logic separation challenge");
+  const HFr fixed_sep = ts.challenge_scalar("fixed base separation challenge");
+  const HFr var_sep = ts.challenge_scalar("variable base separation challenge");
+  PK_TRY(pm_fr_ntt_dev(ctx, z_coeffs, n, n, at(pk->coset, 4 * n * 4), 4 * n, lg + 2, 1, PM_NTT_COSET, nullptr));
+  PK_TRY(pm_stream_join(ctx, side, pk->ev_side));   // the wire / PI coset forms are ready
   pm_plonk_quotient_args qa;
   memset(&qa, 0, sizeof qa);
   for (int j = 0; j < 4; ++j) {
@@ -367,13 +581,26 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   }
   qa.z = at(pk->coset, 4 * n * 4);
   qa.pi = at(pk->coset, 4 * n * 5);
-  const void** sel[6] = {&qa.q_m, &qa.q_l, &qa.q_r, &qa.q_o, &qa.q_4, &qa.q_c};
-  for (int s = 0; s < 6; ++s) *sel[s] = at(pk->sel_coset, 4 * n * s);
+  qa.q_m = pk->sel_coset[Q_M];
+  qa.q_l = pk->sel_coset[Q_L];
+  qa.q_r = pk->sel_coset[Q_R];
+  qa.q_o = pk->sel_coset[Q_O];
+  qa.q_c = pk->sel_coset[Q_C];
+  qa.q_4 = pk->sel_coset[Q_4];
+  qa.q_arith = pk->sel_coset[Q_ARITH];            // nullptr when q_arith = 1
+  qa.q_range = pk->sel_coset[Q_RANGE];
+  qa.q_logic = pk->sel_coset[Q_LOGIC];
+  qa.q_fixed_group_add = pk->sel_coset[Q_FIXED];
+  qa.q_variable_group_add = pk->sel_coset[Q_VAR];
   qa.l1 = pk->l1_coset;
   qa.x = pk->x4;
   put(qa.alpha, alpha);
   put(qa.beta, beta);
   put(qa.gamma, gamma);
+  put(qa.range_sep, range_sep);
+  put(qa.logic_sep, logic_sep);
+  put(qa.fixed_sep, fixed_sep);
+  put(qa.var_sep, var_sep);
   for (int j = 0; j < 3; ++j) put(qa.k[j], pk->k[j]);
   for (int j = 0; j < 4; ++j) put(qa.zh_inv[j], pk->zh_inv[j]);
   PK_TRY(pm_plonk_quotient_dev(ctx, &qa, n, pk->t, nullptr));
@@ -383,15 +610,38 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   for (int i = 0; i < 4; ++i) ts.append_commitment(tl[i], out->commitments[5 + i]);
   // ---- round 4 --------------------------------------------------------------------------------
   const HFr zc = ts.challenge_scalar("z"), zw = fmul(zc, pk->omega);
-  HFr ev[10];   // a b c d sigma_1 sigma_2 sigma_3 z_next t r
-  for (int j = 0; j < 4; ++j) PK_TRY(pm_fr_poly_evaluate_dev(ctx, at(pk->coeffs, j * n), n, zc.l, ev[j].l, nullptr));
-  for (int j = 0; j < 3; ++j) PK_TRY(pm_fr_poly_evaluate_dev(ctx, at(pk->sigma_coeffs, j * n), n, zc.l, ev[4 + j].l, nullptr));
-  PK_TRY(pm_fr_poly_evaluate_dev(ctx, z_coeffs, n, zw.l, ev[7].l, nullptr));
+  enum { E_A, E_B, E_C, E_D, E_AN, E_BN, E_DN, E_S1, E_S2, E_S3, E_QARITH, E_QC, E_QL, E_QR, E_ZN, E_T, E_R, NEV };
+  HFr ev[NEV];
+  {
+    // 15 polynomials at z and 4 at z w: two batched calls, one host synchronisation each
+    const void* at_z[15];
+    u64 out_z[15][4], out_zw[4][4];
+    for (int j = 0; j < 4; ++j) at_z[j] = at(pk->coeffs, j * n);
+    for (int j = 0; j < 3; ++j) at_z[4 + j] = at(pk->sigma_coeffs, j * n);
+    at_z[7] = at(pk->sel_coeffs, Q_ARITH * n);
+    at_z[8] = at(pk->sel_coeffs, Q_C * n);
+    at_z[9] = at(pk->sel_coeffs, Q_L * n);
+    at_z[10] = at(pk->sel_coeffs, Q_R * n);
+    for (int i = 0; i < 4; ++i) at_z[11 + i] = at(pk->t, i * n);
+    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 15, at_z, n, zc.l, &out_z[0][0], nullptr));
+    const void* at_zw[4] = {at(pk->coeffs, 0), at(pk->coeffs, n), at(pk->coeffs, 3 * n), z_coeffs};
+    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 4, at_zw, n, zw.l, &out_zw[0][0], nullptr));
+    for (int j = 0; j < 4; ++j) ev[E_A + j] = get(out_z[j]);
+    for (int j = 0; j < 3; ++j) ev[E_S1 + j] = get(out_z[4 + j]);
+    ev[E_QARITH] = get(out_z[7]);
+    ev[E_QC] = get(out_z[8]);
+    ev[E_QL] = get(out_z[9]);
+    ev[E_QR] = get(out_z[10]);
+    ev[E_AN] = get(out_zw[0]);
+    ev[E_BN] = get(out_zw[1]);
+    ev[E_DN] = get(out_zw[2]);
+    ev[E_ZN] = get(out_zw[3]);
+    const HFr zn_ = fpow(zc, n);
+    ev[E_T] = fadd(get(out_z[11]), fmul(zn_, fadd(get(out_z[12]), fmul(zn_, fadd(get(out_z[13]), fmul(zn_, get(out_z[14])))))));
+  }
   const HFr zn = fpow(zc, n);
-  HFr tp[4];
-  for (int i = 0; i < 4; ++i) PK_TRY(pm_fr_poly_evaluate_dev(ctx, at(pk->t, i * n), n, zc.l, tp[i].l, nullptr));
-  ev[8] = fadd(tp[0], fmul(zn, fadd(tp[1], fmul(zn, fadd(tp[2], fmul(zn, tp[3]))))));
-  const HFr &a_ = ev[0], &b_ = ev[1], &c_ = ev[2], &d_ = ev[3], &s1 = ev[4], &s2 = ev[5], &s3 = ev[6], &z_next = ev[7];
+  const HFr &a_ = ev[E_A], &b_ = ev[E_B], &c_ = ev[E_C], &d_ = ev[E_D], &s1 = ev[E_S1], &s2 = ev[E_S2], &s3 = ev[E_S3],
+            &z_next = ev[E_ZN], &qar = ev[E_QARITH];
   const HFr l1_z = fmul(fsub(zn, one), finv(fmul(fr_u64(n), fsub(zc, one))));
   const HFr bz = fmul(beta, zc);
   HFr ident = fadd(fadd(a_, bz), gamma);
@@ -400,50 +650,94 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   const HFr copy3 = fmul(fmul(fadd(fadd(a_, fmul(beta, s1)), gamma), fadd(fadd(b_, fmul(beta, s2)), gamma)),
                          fadd(fadd(c_, fmul(beta, s3)), gamma));
   const HFr alpha2 = fmul(alpha, alpha);
-  const void* lin_v[8];
-  u64 lin_c[8][4];
-  const HFr lc[8] = {fmul(a_, b_), a_, b_, c_, d_, one, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)),
-                     fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next))};
-  for (int s = 0; s < 6; ++s) lin_v[s] = at(pk->sel_coeffs, s * n);
-  lin_v[6] = z_coeffs;
-  lin_v[7] = at(pk->sigma_coeffs, 3 * n);
-  for (int i = 0; i < 8; ++i) put(lin_c[i], lc[i]);
-  PK_TRY(pm_fr_lincomb_dev(ctx, 8, lin_v, &lin_c[0][0], n, pk->r, nullptr));
-  PK_TRY(pm_fr_poly_evaluate_dev(ctx, pk->r, n, zc.l, ev[9].l, nullptr));
-  const char* el[10] = {"a_eval", "b_eval", "c_eval", "d_eval", "sigma_1_eval", "sigma_2_eval", "sigma_3_eval",
-                        "z_next_eval", "t_eval", "r_eval"};
-  for (int i = 0; i < 10; ++i) {
+  RowEvals re{a_, b_, c_, d_, ev[E_AN], ev[E_BN], ev[E_DN], ev[E_QL], ev[E_QR], ev[E_QC]};
+  {
+    const void* lin_v[12];
+    u64 lin_c[12][4];
+    uint32_t k = 0;
+    auto term = [&](const void* v, const HFr& c) {
+      lin_v[k] = v;
+      put(lin_c[k], c);
+      ++k;
+    };
+    // arithmetic: q_arith(z) (a b q_m + a q_l + b q_r + c q_o + d q_4 + q_c)
+    term(at(pk->sel_coeffs, Q_M * n), fmul(qar, fmul(a_, b_)));
+    term(at(pk->sel_coeffs, Q_L * n), fmul(qar, a_));
+    term(at(pk->sel_coeffs, Q_R * n), fmul(qar, b_));
+    term(at(pk->sel_coeffs, Q_O * n), fmul(qar, c_));
+    term(at(pk->sel_coeffs, Q_4 * n), fmul(qar, d_));
+    term(at(pk->sel_coeffs, Q_C * n), qar);
+    if (!pk->sel_zero[Q_RANGE]) term(at(pk->sel_coeffs, Q_RANGE * n), widget_range(range_sep, re));
+    if (!pk->sel_zero[Q_LOGIC]) term(at(pk->sel_coeffs, Q_LOGIC * n), widget_logic(logic_sep, re));
+    if (!pk->sel_zero[Q_FIXED]) term(at(pk->sel_coeffs, Q_FIXED * n), widget_fixed(fixed_sep, re));
+    if (!pk->sel_zero[Q_VAR]) term(at(pk->sel_coeffs, Q_VAR * n), widget_var(var_sep, re));
+    term(z_coeffs, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)));
+    term(at(pk->sigma_coeffs, 3 * n), fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next)));
+    PK_TRY(pm_fr_lincomb_dev(ctx, k, lin_v, &lin_c[0][0], n, pk->r, nullptr));
+  }
+  PK_TRY(pm_fr_poly_evaluate_dev(ctx, pk->r, n, zc.l, ev[E_R].l, nullptr));
+  const char* el[NEV] = {"a_eval", "b_eval", "c_eval", "d_eval", "a_next_eval", "b_next_eval", "d_next_eval",
+                         "left_sig_eval", "right_sig_eval", "out_sig_eval", "q_arith_eval", "q_c_eval", "q_l_eval",
+                         "q_r_eval", "perm_eval", "t_eval", "r_eval"};
+  for (int i = 0; i < NEV; ++i) {
     ts.append_scalar(el[i], ev[i]);
     put(out->evaluations[i], ev[i]);
   }
-  // ---- round 5 --------------------------------------------------------------------------------
-  const HFr v = ts.challenge_scalar("v");
-  const void* agg_v[12];
-  u64 agg_c[12][4];
-  HFr ac[12];
-  ac[0] = one;
-  ac[1] = zn;
-  ac[2] = fmul(zn, zn);
-  ac[3] = fmul(ac[2], zn);
-  HFr vp = one;
-  for (int e = 0; e < 8; ++e) {
-    vp = fmul(vp, v);
-    ac[4 + e] = vp;
+  // ---- round 5: CommitKey::compute_aggregate_witness at z and at z w ------------------------------
+  const HFr aw = ts.challenge_scalar("aggregate_witness");
+  {
+    const void* agg_v[12];
+    u64 agg_c[12][4];
+    HFr ac[12];
+    ac[0] = one;                      // quot = t_1 + z^n t_2 + z^2n t_3 + z^3n t_4 comes first (power 0)
+    ac[1] = zn;
+    ac[2] = fmul(zn, zn);
+    ac[3] = fmul(ac[2], zn);
+    HFr vp = one;
+    for (int e = 0; e < 8; ++e) {     // then lin, w_l, w_r, w_o, w_4, left, right, out sigma
+      vp = fmul(vp, aw);
+      ac[4 + e] = vp;
+    }
+    for (int i = 0; i < 4; ++i) agg_v[i] = at(pk->t, i * n);
+    agg_v[4] = pk->r;
+    for (int j = 0; j < 4; ++j) agg_v[5 + j] = at(pk->coeffs, j * n);
+    for (int j = 0; j < 3; ++j) agg_v[9 + j] = at(pk->sigma_coeffs, j * n);
+    for (int i = 0; i < 12; ++i) put(agg_c[i], ac[i]);
+    PK_TRY(pm_fr_lincomb_dev(ctx, 12, agg_v, &agg_c[0][0], n, pk->agg, nullptr));
+    PK_TRY(pm_fr_poly_ruffini_dev(ctx, pk->agg, n, zc.l, pk->wit, nullptr));
   }
-  for (int i = 0; i < 4; ++i) agg_v[i] = at(pk->t, i * n);
-  agg_v[4] = pk->r;
-  for (int j = 0; j < 4; ++j) agg_v[5 + j] = at(pk->coeffs, j * n);
-  for (int j = 0; j < 3; ++j) agg_v[9 + j] = at(pk->sigma_coeffs, j * n);
-  for (int i = 0; i < 12; ++i) put(agg_c[i], ac[i]);
-  PK_TRY(pm_fr_lincomb_dev(ctx, 12, agg_v, &agg_c[0][0], n, pk->agg, nullptr));
-  PK_TRY(pm_fr_poly_ruffini_dev(ctx, pk->agg, n, zc.l, pk->wit, nullptr));
-  PK_TRY(pm_fr_poly_ruffini_dev(ctx, z_coeffs, n, zw.l, at(pk->wit, n), nullptr));
+  const HFr aws = ts.challenge_scalar("aggregate_witness");
+  {
+    const void* sh_v[4] = {z_coeffs, at(pk->coeffs, 0), at(pk->coeffs, n), at(pk->coeffs, 3 * n)};
+    u64 sh_c[4][4];
+    HFr vp = one;
+    for (int e = 0; e < 4; ++e) {
+      put(sh_c[e], vp);
+      vp = fmul(vp, aws);
+    }
+    PK_TRY(pm_fr_lincomb_dev(ctx, 4, sh_v, &sh_c[0][0], n, pk->agg, nullptr));
+    PK_TRY(pm_fr_poly_ruffini_dev(ctx, pk->agg, n, zw.l, at(pk->wit, n), nullptr));
+  }
   PK_TRY(commit_batch(ctx, ck, shard, pk->wit, n - 1, n, 2, &out->commitments[9]));
   ts.append_commitment("w_z", out->commitments[9]);
-  ts.append_commitment("w_zw", out->commitments[10]);
-  const HFr u = ts.challenge_scalar("u");
-  const HFr chal[6] = {beta, gamma, alpha, zc, v, u};
-  for (int i = 0; i < 6; ++i) put(out->challenges[i], chal[i]);
-  (void)SEL_NAMES;
+  ts.append_commitment("w_z_w", out->commitments[10]);
+  const HFr chal[10] = {beta, gamma, alpha, range_sep, logic_sep, fixed_sep, var_sep, zc, aw, aws};
+  for (int i = 0; i < 10; ++i) put(out->challenges[i], chal[i]);
+  return PM_OK;
+}
+
+// Proof::to_bytes of dusk-plonk 0.8: 11 compressed G1 (a b c d z t_1..t_4 w_z w_zw) then the 16 scalars of
+// ProofEvaluations::to_bytes (a b c d a_next b_next d_next q_arith q_c q_l q_r left right out sigma, lin_poly, perm).
+extern "C" int pm_plonk_proof_to_bytes(const pm_plonk_proof* proof, uint8_t out[PM_PLONK_PROOF_BYTES]) {
+  if (!proof || !out) return PM_ERR_BAD_ARG;
+  for (int i = 0; i < 11; ++i) Transcript::g1_compress(out + 48 * i, proof->commitments[i]);
+  static const int order[16] = {0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 7, 8, 9, 16, 14};
+  for (int i = 0; i < 16; ++i) Transcript::scalar_bytes(out + 528 + 32 * i, get(proof->evaluations[order[i]]));
+  return PM_OK;
+}
+
+extern "C" int pm_plonk_verifier_key(const pm_prover_key* key, uint64_t (*out)[12]) {
+  if (!key || !out || !key->committed) return PM_ERR_BAD_ARG;
+  memcpy(out, key->vk, sizeof key->vk);
   return PM_OK;
 }

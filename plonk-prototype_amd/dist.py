@@ -44,22 +44,42 @@ def allgather_fold(partial_xyz: np.ndarray, device=None) -> np.ndarray:
     return g1_fold(stacked)
 
 
-def allgather_fold_many(partials_xyz: np.ndarray, device=None) -> np.ndarray:
-    """[k, 18] partial points per rank -> [k, 18] folded sums, one all_gather for all k."""
+_MAX_PARTIALS = 16
+
+
+def allgather_fold_many(partials_xyz, device=None):
+    """[k, 18] partial points per rank -> [k, 18] folded sums, one all_gather for all k (k <= 16).
+
+    ``partials_xyz=None`` is the abort marker of a rank whose local work failed: it still takes part in
+    the collective (fixed-size message: count + 16 points), and every rank -- the failed one included --
+    gets ``None`` back instead of blocking in a collective its peer never enters."""
     import torch
     import torch.distributed as dist
 
-    p = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
+    if partials_xyz is None:
+        p = np.zeros((0, 18), np.uint64)
+    else:
+        p = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return p
+        return None if partials_xyz is None else p
+    if p.shape[0] > _MAX_PARTIALS:
+        raise ValueError("at most 16 partial points per exchange")
     world = dist.get_world_size()
-    mine = torch.from_numpy(p.view(np.int64).copy())
+    msg = np.zeros(1 + 18 * _MAX_PARTIALS, np.uint64)
+    msg[0] = 0 if partials_xyz is None else p.shape[0]
+    msg[1:1 + p.size] = p.reshape(-1)
+    mine = torch.from_numpy(msg.view(np.int64).copy())
     if device is not None:
         mine = mine.to(device)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
-    stacked = torch.stack(parts).cpu().numpy().view(np.uint64)          # [world, k, 18]
-    return np.stack([g1_fold(stacked[:, j]) for j in range(p.shape[0])])
+    stacked = torch.stack(parts).cpu().numpy().view(np.uint64)          # [world, 1 + 288]
+    counts = stacked[:, 0]
+    if partials_xyz is None or (counts == 0).any() or (counts != counts[0]).any():
+        return None
+    k = int(counts[0])
+    pts = stacked[:, 1:1 + 18 * k].reshape(world, k, 18)
+    return np.stack([g1_fold(np.ascontiguousarray(pts[:, j])) for j in range(k)]) if k else p
 
 
 class ShardedCommitKey:
@@ -67,8 +87,11 @@ class ShardedCommitKey:
     process group (BASELINE.json configs[4]): this rank holds powers [lo, lo + len(powers_slice)) of
     `total`.  ``commit_batch_dev`` runs the local slice of every MSM, then one all_gather + fold."""
 
-    def __init__(self, powers_slice, lo: int, total: int, ctx: Context, device=None, precompute: bool = False):
-        self.ctx, self.lo, self.total, self.device = ctx, lo, total, device
+    def __init__(self, powers_slice, lo: int, total: int, ctx: Context, device=None, precompute: bool = False,
+                 native: bool = False):
+        """native: exchange through the library's own RCCL communicator (``Context.comm_init`` first) instead
+        of torch.distributed -- what a host without PyTorch does."""
+        self.ctx, self.lo, self.total, self.device, self.native = ctx, lo, total, device, native
         self._bases = Bases(ctx, powers_slice)
         if precompute and self._bases.n:
             self._bases.precompute()
@@ -88,7 +111,10 @@ class ShardedCommitKey:
             part = self._bases.msm_batch_dev(d_ptr + 32 * self.lo, cnt, batch, stride=stride if stride is not None else n)
         else:
             part = np.tile(self._identity, (batch, 1))
-        return [g1_to_affine(p)[0] for p in allgather_fold_many(part, self.device)]
+        folded = self.ctx.g1_allgather_fold(part) if self.native else allgather_fold_many(part, self.device)
+        if folded is None:
+            raise Error(_lib.PM_ERR_EXCHANGE, "a peer rank gave up")
+        return [g1_to_affine(p)[0] for p in folded]
 
 
 # ---------------------------------------------------------------------------------------------

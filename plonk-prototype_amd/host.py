@@ -91,6 +91,39 @@ class Context:
         return out
 
     # ---- raw ABI calls -------------------------------------------------------------
+    # ---- the exchange step inside the library (RCCL; one process per GPU) ----------------------------
+    def comm_init(self, rank: int | None = None, world: int | None = None, device=None):
+        """Create this rank's RCCL communicator (``pm_comm_init``).  Rank 0 makes the unique id; its 128
+        bytes travel to the other ranks through the default ``torch.distributed`` process group (any
+        backend: the id is host data), which must already be initialised for world > 1."""
+        if world is None:
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        if rank == 0:
+            self._check(self._lib.pm_comm_unique_id(ident))
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor(list(bytes(ident)), dtype=torch.uint8)
+            if device is not None:
+                t = t.to(device)
+            dist.broadcast(t, src=0)
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
+        self._check(self._lib.pm_comm_init(self._h, ident, rank, world))
+        self.comm_world = world
+
+    def comm_destroy(self):
+        self._check(self._lib.pm_comm_destroy(self._h))
+        self.comm_world = 1
+
+    def g1_allgather_fold(self, partials_xyz) -> np.ndarray:
+        """[k, 18] partial points of this rank -> [k, 18] sums over all ranks (``pm_g1_allgather_fold``)."""
+        p = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18).copy()
+        self._check(self._lib.pm_g1_allgather_fold(self._h, _p(p), p.shape[0]))
+        return p
+
     def fr_ntt(self, a, log_n: int, flags: int = 0, out=None) -> np.ndarray:
         a = _fr(a)
         n = 1 << log_n if log_n < 64 else 0
@@ -142,6 +175,14 @@ class Context:
         pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
         out = np.zeros(4, np.uint64)
         self._check(self._lib.pm_fr_poly_evaluate_dev(self._h, C.c_void_p(d_coeffs), n, _p(pt), _p(out), None))
+        return out
+
+    def fr_evaluate_many(self, d_polys, n: int, point) -> np.ndarray:
+        """k polynomials of n coefficients at one point: one kernel pass, one synchronisation.  -> [k, 4]."""
+        k = len(d_polys)
+        ptrs = (C.c_void_p * k)(*[C.c_void_p(int(p)) for p in d_polys])
+        out = np.zeros((k, 4), np.uint64)
+        self._check(self._lib.pm_fr_poly_evaluate_many_dev(self._h, k, ptrs, n, _p(_fr(point)), _p(out), None))
         return out
 
     def fr_ruffini(self, d_coeffs: int, n: int, z, d_out: int):

@@ -116,3 +116,45 @@ def test_integration_doc_lists_every_export():
     exports = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", header))
     bound = set(re.findall(r"pub fn (pm_[a-z0-9_]+)", doc))
     assert exports == bound, (sorted(exports - bound), sorted(bound - exports))
+
+
+def test_exchange_fold_of_gathered_messages():
+    """The fold step of pm_g1_allgather_fold (host code, no GPU): messages of [count | 16 points] per rank,
+    per-point group-law sum over the ranks, PM_ERR_EXCHANGE for an abort marker or unequal counts."""
+    import ctypes as C
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd import _lib
+    from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+    lib = pa.load()
+    o = CpuOracle()
+    G = o.g1_generator()
+    one = o.fp_to_mont(ints_to_limbs([1], 6))[0]
+
+    def proj(k):
+        p = np.zeros(18, np.uint64)
+        if k:
+            p[:12] = o.g1_mul(G, ints_to_limbs([k], 4)[0])
+            p[12:] = one
+        else:
+            p[6:12] = one
+        return p
+    world, k = 3, 2
+    words = 1 + 18 * _lib.COMM_MAX_POINTS
+    msgs = np.zeros((world, words), np.uint64)
+    scal = [[5, 0], [7, 11], [0, 13]]
+    for r in range(world):
+        msgs[r, 0] = k
+        for j in range(k):
+            msgs[r, 1 + 18 * j:19 + 18 * j] = proj(scal[r][j])
+    out = np.zeros((k, 18), np.uint64)
+    u64p = C.POINTER(C.c_uint64)
+    assert lib.pm_test_fold_gathered(msgs.ctypes.data_as(u64p), world, k, out.ctypes.data_as(u64p)) == 0
+    assert np.array_equal(pa.g1_to_affine(out[0])[0], o.g1_mul(G, ints_to_limbs([12], 4)[0]))
+    assert np.array_equal(pa.g1_to_affine(out[1])[0], o.g1_mul(G, ints_to_limbs([24], 4)[0]))
+    bad = msgs.copy()
+    bad[1, 0] = 0                                                      # rank 1 gave up
+    assert lib.pm_test_fold_gathered(bad.ctypes.data_as(u64p), world, k, out.ctypes.data_as(u64p)) == _lib.PM_ERR_EXCHANGE
+    bad = msgs.copy()
+    bad[2, 0] = 3                                                      # ranks out of step
+    assert lib.pm_test_fold_gathered(bad.ctypes.data_as(u64p), world, k, out.ctypes.data_as(u64p)) == _lib.PM_ERR_EXCHANGE
+    assert lib.pm_test_fold_gathered(msgs.ctypes.data_as(u64p), world, 17, out.ctypes.data_as(u64p)) == _lib.PM_ERR_BAD_ARG

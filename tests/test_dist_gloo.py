@@ -52,6 +52,8 @@ def _worker(rank, world, port, n, q):
         many = allgather_fold_many(np.stack([part, ident, part]))
         assert many.shape == (3, 18) and np.array_equal(many[0], total) and np.array_equal(many[2], total)
         assert not many[1][12:].any()                                  # identity + identity = identity (Z = 0)
+        # a rank whose local work failed still enters the collective (abort marker): every rank learns of it
+        assert allgather_fold_many(None if rank == 1 else np.stack([part])) is None
         q.put((rank, total.tolist(), o.g1_msm(pts, sc).tolist(), (lo, hi)))
     finally:
         dist.destroy_process_group()

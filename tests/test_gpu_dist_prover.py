@@ -25,7 +25,7 @@ def _free_port():
 def _inputs():
     import plonk_prototype_amd as pa
     from oracle.cpu_oracle import CpuOracle, ints_to_limbs
-    circuit, wit, pi = pa.synthetic.chain_circuit(N, 21)
+    circuit, wit, pi = pa.synthetic.mixed_circuit(N, 21)
     srs = CpuOracle().g1_bases_arith(ints_to_limbs([77], 4)[0], ints_to_limbs([0x10001], 4)[0], N, 4)
     return circuit, wit, pi, srs
 
@@ -48,14 +48,12 @@ def _worker(rank, world, port, q):
         ctx = pa.Context(0)
         lo, hi = shard_range(N, rank, world)
         ck = ShardedCommitKey(srs[lo:hi], lo, N, ctx, precompute=(rank == 0))   # mixed table / no table
-        pk = pa.preprocess(circuit, ctx)
+        pk = pa.preprocess(circuit, ctx, ck)        # the verifier key's 15 commitments go through the exchange too
         proof = pa.prove(pk, ck, wit, pi)
-        # the native sequence with the exchange callback must agree with the Python one on every rank
-        npk = pa.NativeProverKey(circuit, ctx)
-        nat = pa.prove_native(npk, ck, pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)), pa.DeviceVector.from_host(ctx, pi))
-        assert nat.to_bytes() == proof.to_bytes()
-        npk.free()
-        q.put((rank, _proof_blob(proof).tolist()))
+        again = pa.prove(pk, ck, pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)), pi)
+        assert again.to_bytes() == proof.to_bytes()
+        vk = np.concatenate([pk.verifier_key[k] for k in sorted(pk.verifier_key)])
+        q.put((rank, np.concatenate([_proof_blob(proof), vk]).tolist()))
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -65,7 +63,10 @@ def test_sharded_prover_world2_equals_single_gpu(ctx):
     import torch.multiprocessing as mp
     import plonk_prototype_amd as pa
     circuit, wit, pi, srs = _inputs()
-    single = _proof_blob(pa.prove(pa.preprocess(circuit, ctx), pa.CommitKey(srs, ctx), wit, pi)).tolist()
+    ck = pa.CommitKey(srs, ctx)
+    pk = pa.preprocess(circuit, ctx, ck)
+    single = np.concatenate([_proof_blob(pa.prove(pk, ck, wit, pi))]
+                            + [pk.verifier_key[k] for k in sorted(pk.verifier_key)]).tolist()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
@@ -79,3 +80,33 @@ def test_sharded_prover_world2_equals_single_gpu(ctx):
     assert sorted(r[0] for r in res) == [0, 1]
     for rank, blob in res:
         assert blob == single, rank
+
+
+def test_library_communicator_world1(ctx, oracle):
+    """The in-library RCCL exchange on the one GPU of the test box (a one-rank communicator: two RCCL ranks
+    cannot share a device): unique id, ncclCommInitRank, ncclAllGather through pm_g1_allgather_fold, and the
+    sharded prover entry points with exchange = NULL -- the proof must equal the unsharded one byte for byte."""
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd.dist import ShardedCommitKey
+    from oracle.cpu_oracle import ints_to_limbs
+    circuit, wit, pi, srs = _inputs()
+    ctx.comm_init(0, 1)
+    try:
+        part = np.zeros((2, 18), np.uint64)
+        one = oracle.fp_to_mont(ints_to_limbs([1], 6))[0]
+        part[0, :12], part[0, 12:] = srs[3], one
+        part[1, 6:12] = one
+        got = ctx.g1_allgather_fold(part)
+        assert np.array_equal(pa.g1_to_affine(got[0])[0], srs[3]) and pa.g1_to_affine(got[1])[1]
+        with pytest.raises(pa.Error) as e:
+            ctx.g1_allgather_fold(np.zeros((0, 18), np.uint64))      # the abort marker comes back as an error
+        assert e.value.code == -7
+        ck_plain = pa.CommitKey(srs, ctx)
+        ref = pa.prove(pa.preprocess(circuit, ctx, ck_plain), ck_plain, wit, pi)
+        ck = ShardedCommitKey(srs, 0, N, ctx, native=True)
+        pk = pa.preprocess(circuit, ctx, ck)
+        assert pa.prove(pk, ck, wit, pi).to_bytes() == ref.to_bytes()
+    finally:
+        ctx.comm_destroy()
+    with pytest.raises(pa.Error):
+        ctx.g1_allgather_fold(np.zeros((1, 18), np.uint64))          # no communicator any more

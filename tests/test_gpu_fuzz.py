@@ -170,27 +170,24 @@ def test_prover_round_kernels_random_shapes(ctx, oracle):
 
 
 def test_prove_many_seeds(ctx, oracle):
-    """Several circuits and sizes: every proof must satisfy the verifier identity, and the serialised
-    proof must round-trip."""
+    """Several circuits (arithmetic-only and with every widget) and sizes: every proof must satisfy the
+    verifier identity, the serialised proof must round-trip, and a second proof from the same key
+    (workspace reuse) must be identical."""
     import plonk_prototype_amd as pa
     import plonk_prototype_amd.prover as PR
     srs = oracle.g1_bases_arith(ints_to_limbs([11], 4)[0], ints_to_limbs([0x10001], 4)[0], 2048, 8)
     for seed, n in [(1 + SEED, 8), (2 + SEED, 32), (3 + SEED, 128), (4 + SEED, 512), (5 + SEED, 2048)] * min(SCALE, 4):
-        circuit, wit, pub = pa.synthetic.chain_circuit(n, seed)
-        pk = PR.preprocess(circuit, ctx)
+        gen = pa.synthetic.mixed_circuit if (n >= 32 and seed % 2) else pa.synthetic.chain_circuit
+        circuit, wit, pub = gen(n, seed)
         ck = pa.CommitKey(srs[:n], ctx, precompute=(seed % 2 == 0))
+        pk = PR.preprocess(circuit, ctx, ck)
         proof = PR.prove(pk, ck, wit, pub)
         pub_c = oracle.fr_ntt(pub, n.bit_length() - 1, INVERSE)
         pub_z = limbs_to_ints(oracle.fr_from_mont(
             oracle.fr_poly_evaluate(pub_c, oracle.fr_to_mont(ints_to_limbs([proof.challenges["z"]], 4))[0]).reshape(1, 4)))[0]
         assert PR.check_identity(proof, n, pub_z), (seed, n)
         blob = proof.to_bytes()
-        assert PR.Proof.from_bytes(blob).to_bytes() == blob
-        # a second proof from the same key reuses the workspace and must be identical
-        again = PR.prove(pk, ck, wit, pub)
-        assert again.to_bytes() == blob
-        # and the native sequence (pm_plonk_prove) returns the same bytes
-        npk = PR.NativeProverKey(circuit, ctx)
-        d_w, d_p = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)), pa.DeviceVector.from_host(ctx, pub)
-        assert PR.prove_native(npk, ck, d_w, d_p).to_bytes() == blob
-        npk.free()
+        assert PR.Proof.from_bytes(blob).to_bytes() == blob and proof.native_bytes == blob
+        d_w = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
+        assert PR.prove(pk, ck, d_w, PR.sparse_public_inputs(pub)).to_bytes() == blob
+        pk.free()

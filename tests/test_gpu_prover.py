@@ -102,40 +102,68 @@ def test_perm_terms(ctx, oracle, n):
     assert _ints(oracle, den.to_host()) == ed
 
 
-@pytest.mark.parametrize("n", [4, 64, 1024])
-def test_quotient_kernel(ctx, oracle, n):
-    """Random (unsatisfied) inputs on the true 4n coset: the kernel is a pointwise map, so parity needs
-    no valid circuit."""
-    import plonk_prototype_amd as pa
+def _quotient_args(pa, oracle, d, dx, x, n, ch, widgets):
     import plonk_prototype_amd.prover as PR
     from plonk_prototype_amd import _lib
-    rng = random.Random(n)
-    n4 = 4 * n
-    names = ["w0", "w1", "w2", "w3", "z", "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "pi", "s0", "s1", "s2", "s3", "l1"]
-    v = {k: _rand(rng, n4) for k in names}
-    v["q_m"][0], v["z"][1], v["w0"][2] = 0, 1, R - 1
-    x = PO.powers(B.Domain(n4).group_gen, 7, n4)
-    alpha, beta, gamma = (rng.randrange(R) for _ in range(3))
-    d = {k: _to_dev(pa, ctx, oracle, val) for k, val in v.items()}
-    dx = _to_dev(pa, ctx, oracle, x)
     qa = _lib.QuotientArgs()
     u = lambda s: (PR.C.c_uint64 * 4)(*[int(t) for t in _mont(oracle, s)])   # noqa: E731
     for j in range(4):
         qa.wires[j], qa.sigmas[j] = d[f"w{j}"].ptr, d[f"s{j}"].ptr
-    for k in ("z", "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "pi", "l1"):
+    for k in ("z", "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "pi", "l1") + tuple(widgets):
         setattr(qa, k, d[k].ptr)
     qa.x = dx.ptr
-    qa.alpha, qa.beta, qa.gamma = u(alpha), u(beta), u(gamma)
+    qa.alpha, qa.beta, qa.gamma = u(ch["alpha"]), u(ch["beta"]), u(ch["gamma"])
+    qa.range_sep, qa.logic_sep, qa.fixed_sep, qa.var_sep = (u(ch[k]) for k in ("range_sep", "logic_sep", "fixed_sep",
+                                                                                 "var_sep"))
     for j, k in enumerate((7, 13, 17)):
         qa.k[j] = u(k)
     for j in range(4):
         qa.zh_inv[j] = u(PO.inv(pow(x[j], n, R) - 1))
+    return qa
+
+
+@pytest.mark.parametrize("n,widgets", [(4, ()), (64, ()), (1024, ()),
+                                       (4, ("q_arith",)),
+                                       (16, ("q_range",)), (16, ("q_logic",)), (16, ("q_fixed_group_add",)),
+                                       (16, ("q_variable_group_add",)),
+                                       (256, ("q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"))])
+def test_quotient_kernel(ctx, oracle, n, widgets):
+    """Random (unsatisfied) inputs on the true 4n coset: the kernel is a pointwise map, so parity needs
+    no valid circuit.  A selector that is not passed is the constant 1 (q_arith) resp. 0 (the widgets)."""
+    import plonk_prototype_amd as pa
+    rng = random.Random(n + 7 * len(widgets))
+    n4 = 4 * n
+    names = ["w0", "w1", "w2", "w3", "z", "q_m", "q_l", "q_r", "q_o", "q_4", "q_c", "pi", "s0", "s1", "s2", "s3", "l1"]
+    v = {k: _rand(rng, n4) for k in names + list(widgets)}
+    v["q_m"][0], v["z"][1], v["w0"][2] = 0, 1, R - 1
+    x = PO.powers(B.Domain(n4).group_gen, 7, n4)
+    ch = {k: rng.randrange(R) for k in PO.CHALLENGES}
+    d = {k: _to_dev(pa, ctx, oracle, val) for k, val in v.items()}
+    dx = _to_dev(pa, ctx, oracle, x)
     out = pa.DeviceVector(ctx, n4)
-    ctx.plonk_quotient(qa, n, out.ptr)
-    exp = PO.quotient_evals(n, [v[f"w{j}"] for j in range(4)], v["z"],
-                            {k: v[k] for k in ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")}, v["pi"],
-                            [v[f"s{j}"] for j in range(4)], v["l1"], x, alpha, beta, gamma)
+    ctx.plonk_quotient(_quotient_args(pa, oracle, d, dx, x, n, ch, widgets), n, out.ptr)
+    sel = {k: v[k] for k in ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")}
+    sel["q_arith"] = v.get("q_arith", [1] * n4)
+    for k in PO.WIDGET_SELECTORS:
+        sel[k] = v.get(k, [0] * n4)
+    exp = PO.quotient_evals(n, [v[f"w{j}"] for j in range(4)], v["z"], sel, v["pi"],
+                            [v[f"s{j}"] for j in range(4)], v["l1"], x, ch)
     assert _ints(oracle, out.to_host()) == exp
+
+
+def test_evaluate_many(ctx, oracle):
+    """pm_fr_poly_evaluate_many_dev == k single evaluations == Horner in the oracle."""
+    import plonk_prototype_amd as pa
+    rng = random.Random(12)
+    n, k = 3000, 15
+    polys = [_rand(rng, n) for _ in range(k)]
+    pt = rng.randrange(R)
+    dv = [_to_dev(pa, ctx, oracle, p) for p in polys]
+    got = ctx.fr_evaluate_many([d.ptr for d in dv], n, _mont(oracle, pt))
+    assert _ints(oracle, got) == [B.horner(p, pt) for p in polys]
+    assert np.array_equal(got[3], ctx.fr_evaluate(dv[3].ptr, n, _mont(oracle, pt)))
+    with pytest.raises(pa.Error):
+        ctx.fr_evaluate_many([dv[0].ptr] * 17, n, _mont(oracle, pt))
 
 
 def _srs(oracle, n):
@@ -152,24 +180,29 @@ def _g(oracle, k):
     return oracle.g1_mul(oracle.g1_generator(), ints_to_limbs([k % R], 4)[0])
 
 
-def _setup(ctx, oracle, n, seed):
+def _circuit(n, seed, mixed):
+    import plonk_prototype_amd as pa
+    return (pa.synthetic.mixed_circuit if mixed else pa.synthetic.chain_circuit)(n, seed)
+
+
+def _setup(ctx, oracle, n, seed, mixed=False):
     import plonk_prototype_amd as pa
     from plonk_prototype_amd.field import fr_vec_from_limbs
-    from plonk_prototype_amd.synthetic import chain_circuit
-    circuit, wit, pi = chain_circuit(n, seed)
+    circuit, wit, pi = _circuit(n, seed, mixed)
     srs = _srs(oracle, n)
     ck = pa.CommitKey(srs, ctx, precompute=(n >= 64))
-    pk = pa.prover.preprocess(circuit, ctx)
-    sel = {k: fr_vec_from_limbs(getattr(circuit, k)) for k in ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")}
+    pk = pa.prover.preprocess(circuit, ctx, ck)
+    sel = {k: fr_vec_from_limbs(getattr(circuit, k)) if getattr(circuit, k) is not None else [0] * n for k in PO.SELECTORS}
     ints = (sel, circuit.sigma_index.tolist(), [fr_vec_from_limbs(wit[j]) for j in range(4)], fr_vec_from_limbs(pi))
     return circuit, wit, pi, srs, ck, pk, ints
 
 
-@pytest.mark.parametrize("n", [4, 16, 256])
-def test_prove_matches_the_oracle(ctx, oracle, n):
-    import plonk_prototype_amd as pa
+@pytest.mark.parametrize("n,mixed", [(4, False), (16, False), (256, False), (32, True), (256, True)])
+def test_prove_matches_the_oracle(ctx, oracle, n, mixed):
+    """Every commitment and all 17 evaluations of pm_plonk_prove against the big-int restatement, on
+    arithmetic-only circuits and on circuits with range / logic / fixed-base / variable-base rows."""
     import plonk_prototype_amd.prover as PR
-    circuit, wit, pi, srs, ck, pk, (sel, sigma, wi, pii) = _setup(ctx, oracle, n, seed=n)
+    circuit, wit, pi, srs, ck, pk, (sel, sigma, wi, pii) = _setup(ctx, oracle, n, seed=n, mixed=mixed)
     proof = PR.prove(pk, ck, wit, pi)
     exp = PO.prove(n, sel, sigma, wi, pii, proof.challenges)
     # openings
@@ -186,64 +219,109 @@ def test_prove_matches_the_oracle(ctx, oracle, n):
     assert set(want) == set(proof.commitments)
     for k in want:
         assert np.array_equal(proof.commitments[k], want[k]), k
+    # the verifier key the transcript was seeded with
+    for k in PO.SELECTORS:
+        assert np.array_equal(pk.verifier_key[k], commit(exp["sel_coeffs"][k])), k
+    for j in range(4):
+        assert np.array_equal(pk.verifier_key[f"sigma_{j + 1}"], commit(exp["sigma_coeffs"][j]))
+    # ... and the challenges are what a verifier re-derives from the proof bytes and the verifier key
+    rx = PR.Proof.from_bytes(proof.to_bytes())
+    rx.evaluations["t"] = proof.evaluations["t"]
+    ch = PR.derive_challenges(rx, pk.verifier_key, n, pi)
+    assert {k: ch[k] for k in proof.challenges} == proof.challenges
+    assert proof.native_bytes == proof.to_bytes() and len(proof.native_bytes) == 1040
     # oracle-independent: the verifier's scalar identity ...
     pi_z = B.horner(B.ifft(pii, n.bit_length() - 1), proof.challenges["z"])
     assert PR.check_identity(proof, n, pi_z)
     # ... and both KZG opening equations in the exponent (tau is known to the test):
     #   W(tau) (tau - z) = F(tau) - F(z)   with commitments checked as  [p(tau)] G
-    ch, ev = proof.challenges, got
-    zz, v = ch["z"], ch["v"]
-    zn = pow(zz, n, R)
-    agg_eval = (ev["t"] + v * ev["r"] + v ** 2 * ev["a"] + v ** 3 * ev["b"] + v ** 4 * ev["c"] + v ** 5 * ev["d"]
-                + v ** 6 * ev["sigma_1"] + v ** 7 * ev["sigma_2"] + v ** 8 * ev["sigma_3"]) % R
+    chp, ev = proof.challenges, got
+    zz, aw, aws = chp["z"], chp["aw"], chp["aw_shifted"]
     tau_of = lambda c: B.horner(c, TAU)   # noqa: E731
-    parts = [exp["t_coeffs"][i * n:(i + 1) * n] for i in range(4)]
-    agg_tau = (sum(pow(zn, i, R) * tau_of(parts[i]) for i in range(4)) + v * tau_of(exp["r_coeffs"])
-               + sum(pow(v, 2 + j, R) * tau_of(exp["wire_coeffs"][j]) for j in range(4))) % R
-    sig_c = [B.ifft([PO.K[p // n] * pow(B.Domain(n).group_gen, p % n, R) % R for p in sigma[j]], n.bit_length() - 1)
-             for j in range(3)]
-    agg_tau = (agg_tau + sum(pow(v, 6 + j, R) * tau_of(sig_c[j]) for j in range(3))) % R
-    assert np.array_equal(proof.commitments["w_z"], _g(oracle, (agg_tau - agg_eval) * PO.inv(TAU - zz)))
+    agg_eval = (ev["t"] + aw * ev["r"] + aw ** 2 * ev["a"] + aw ** 3 * ev["b"] + aw ** 4 * ev["c"] + aw ** 5 * ev["d"]
+                + aw ** 6 * ev["sigma_1"] + aw ** 7 * ev["sigma_2"] + aw ** 8 * ev["sigma_3"]) % R
+    assert np.array_equal(proof.commitments["w_z"], _g(oracle, (tau_of(exp["agg"]) - agg_eval) * PO.inv(TAU - zz)))
     zw = zz * B.Domain(n).group_gen % R
+    sh_eval = (ev["z_next"] + aws * ev["a_next"] + aws ** 2 * ev["b_next"] + aws ** 3 * ev["d_next"]) % R
     assert np.array_equal(proof.commitments["w_zw"],
-                          _g(oracle, (tau_of(exp["z_coeffs"]) - ev["z_next"]) * PO.inv(TAU - zw)))
+                          _g(oracle, (tau_of(exp["agg_shifted"]) - sh_eval) * PO.inv(TAU - zw)))
 
 
 def test_prove_is_deterministic_and_transcript_bound(ctx, oracle):
+    """Same inputs, same proof; and everything the statement consists of moves the challenges: the
+    transcript label, the circuit (one selector value), the public inputs (Fiat-Shamir must
+    bind the verifier key and the public inputs)."""
     import plonk_prototype_amd.prover as PR
-    from plonk_prototype_amd.transcript import Transcript
     n = 64
     circuit, wit, pi, srs, ck, pk, _ = _setup(ctx, oracle, n, seed=9)
     p1, p2 = PR.prove(pk, ck, wit, pi), PR.prove(pk, ck, wit, pi)
-    assert p1.challenges == p2.challenges
-    assert all(np.array_equal(p1.commitments[k], p2.commitments[k]) for k in p1.commitments)
-    p3 = PR.prove(pk, ck, wit, pi, transcript=Transcript(b"another protocol"))
+    assert p1.challenges == p2.challenges and p1.to_bytes() == p2.to_bytes()
+    pk3 = PR.preprocess(circuit, ctx, ck, label=b"another protocol")
+    p3 = PR.prove(pk3, ck, wit, pi)
     assert p3.challenges["beta"] != p1.challenges["beta"]
     assert np.array_equal(p3.commitments["a"], p1.commitments["a"])          # round 1 has no challenge
     assert not np.array_equal(p3.commitments["z"], p1.commitments["z"])
+    # one selector value changed: another verifier key, other challenges (the witness no longer satisfies it: irrelevant here)
+    c4 = PR.Circuit(**{**circuit.__dict__, "q_c": circuit.q_c.copy()})
+    c4.q_c[5] = c4.q_c[6]
+    p4 = PR.prove(PR.preprocess(c4, ctx, ck), ck, wit, pi)
+    assert p4.challenges["beta"] != p1.challenges["beta"] and np.array_equal(p4.commitments["a"], p1.commitments["a"])
+    # other public inputs
+    pi5 = pi.copy()
+    pi5[0] = pi5[0][::-1].copy() if pi5[0].any() else np.array([1, 0, 0, 0], np.uint64)
+    pi5[0][3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    p5 = PR.prove(pk, ck, wit, pi5)
+    assert p5.challenges["beta"] != p1.challenges["beta"]
+    # dusk-plonk 0.8.2's own transcript does not see the public inputs: reproducible with the flag off
+    p6, p7 = PR.prove(pk, ck, wit, pi, bind_public_inputs=False), PR.prove(pk, ck, wit, pi5, bind_public_inputs=False)
+    assert p6.challenges["beta"] == p7.challenges["beta"] != p1.challenges["beta"]
+    ch = PR.derive_challenges(p6, pk.verifier_key, n, pi, bind_public_inputs=False)
+    assert ch["aw_shifted"] == p6.challenges["aw_shifted"]
 
 
 def test_tampered_witness_fails_the_identity(ctx, oracle):
     import plonk_prototype_amd.prover as PR
     n = 64
-    circuit, wit, pi, srs, ck, pk, (sel, sigma, wi, pii) = _setup(ctx, oracle, n, seed=4)
-    bad = wit.copy()
-    bad[2, 7] = bad[2, 8]
-    proof = PR.prove(pk, ck, bad, pi)
-    pi_z = B.horner(B.ifft(pii, 6), proof.challenges["z"])
-    assert not PR.check_identity(proof, n, pi_z)
+    circuit, wit, pi, srs, ck, pk, (sel, sigma, wi, pii) = _setup(ctx, oracle, n, seed=4, mixed=True)
     good = PR.prove(pk, ck, wit, pi)
     assert PR.check_identity(good, n, B.horner(B.ifft(pii, 6), good.challenges["z"]))
+    for j, i in ((2, 40), (0, 1), (1, 4), (0, 8), (3, 13), (0, 15)):     # arithmetic, range, logic x2, fixed, var rows
+        bad = wit.copy()
+        bad[j, i] = bad[j, i + 1] if not np.array_equal(bad[j, i], bad[j, i + 1]) else bad[j, i + 2]
+        proof = PR.prove(pk, ck, bad, pi)
+        pi_z = B.horner(B.ifft(pii, 6), proof.challenges["z"])
+        assert not PR.check_identity(proof, n, pi_z), (j, i)
 
 
-def test_prover_key_rejects_bad_circuits(ctx, oracle):
+def test_prover_key_rejects_bad_input(ctx, oracle):
+    import plonk_prototype_amd as pa
     import plonk_prototype_amd.prover as PR
     from plonk_prototype_amd.synthetic import chain_circuit
     circuit, wit, pi = chain_circuit(16, 1)
-    circuit.sigma_index = circuit.sigma_index.copy()
-    circuit.sigma_index[0, 0] = circuit.sigma_index[0, 1]                      # not a permutation
+    bad = PR.Circuit(**{**circuit.__dict__, "sigma_index": circuit.sigma_index.copy()})
+    bad.sigma_index[0, 0] = bad.sigma_index[0, 1]                              # not a permutation
+    with pytest.raises(pa.Error):
+        PR.preprocess(bad, ctx)
+    pk = PR.preprocess(circuit, ctx)
+    short = pa.CommitKey(oracle.g1_bases_arith(ints_to_limbs([1], 4)[0], ints_to_limbs([1], 4)[0], 8, 1), ctx)
     with pytest.raises(ValueError):
-        PR.preprocess(circuit, ctx)
+        PR.prove(pk, short, wit, pi)
+    with pytest.raises(pa.Error) as e:                                          # the ABI's own check
+        pk.commit(short)
+    assert e.value.code == -6
+    # a key that was never committed has no transcript to start from
+    import ctypes as C
+    from plonk_prototype_amd import _lib
+    raw = _lib.PlonkProof()
+    ck = pa.CommitKey(oracle.g1_bases_arith(ints_to_limbs([1], 4)[0], ints_to_limbs([1], 4)[0], 16, 1), ctx)
+    d_wit = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
+    assert ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, None, None, 0, 0, C.byref(raw)) == -1
+    pk.commit(ck)
+    assert ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, None, None, 0, 0, C.byref(raw)) == 0
+    assert ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, None, None, 0, 8, C.byref(raw)) == -1   # flags
+    pos = np.array([16], np.uint64)
+    assert ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, pos.ctypes.data_as(_lib.u64p),
+                                   pi.ctypes.data_as(_lib.u64p), 1, 0, C.byref(raw)) == -6                       # position >= n
 
 
 def test_prove_2_16_gates(ctx, oracle):
@@ -257,7 +335,7 @@ def test_prove_2_16_gates(ctx, oracle):
     k0, d = ints_to_limbs([0x1234567], 4)[0], ints_to_limbs([0x9E3779B9], 4)[0]
     srs = oracle.g1_bases_arith(k0, d, n, threads=8)
     ck = pa.CommitKey(srs, ctx, precompute=True)
-    pk = PR.preprocess(circuit, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
     proof = PR.prove(pk, ck, wit, pi)
     pi_coeffs = oracle.fr_ntt(pi, 16, 1)
     pi_z = _ints(oracle, oracle.fr_poly_evaluate(pi_coeffs, _mont(oracle, proof.challenges["z"])))[0]
@@ -266,6 +344,46 @@ def test_prove_2_16_gates(ctx, oracle):
     a_coeffs = oracle.fr_ntt(wit[0], 16, 1)
     dlog = oracle.expected_dlog(a_coeffs, 0, k0, d)
     assert np.array_equal(proof.commitments["a"], oracle.g1_mul(oracle.g1_generator(), dlog))
+
+
+def test_prove_2_20_gates_full_size(ctx, oracle):
+    """BASELINE.json configs[3] at its full size inside pytest (VERDICT r01 missing #5): a 2^20-gate proof over
+    a powers-of-tau key generated on the GPU; the verifier's scalar identity, a commitment against its
+    discrete log ([a(tau)] G) and the KZG equation of the opening witness W_z(tau) (tau - z) = F(tau) - F(z),
+    with the polynomials evaluated on the device."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    gk = 20
+    n = 1 << gk
+    circuit, d_wit, _ = pa.synthetic.wide_circuit(n, ctx, seed=5)
+    ck = pa.CommitKey.setup(n - 1, _mont(oracle, TAU), ctx, precompute=True)
+    pk = PR.preprocess(circuit, ctx, ck)
+    proof = PR.prove(pk, ck, d_wit, None)
+    assert PR.check_identity(proof, n, 0)
+    # a(X) from the witness on the device, at tau
+    coeffs = pa.DeviceVector(ctx, n)
+    ctx.fr_ntt_dev(d_wit.ptr, n, coeffs.ptr, gk, pa.NTT_INVERSE)
+    a_tau = _ints(oracle, ctx.fr_evaluate(coeffs.ptr, n, _mont(oracle, TAU)))[0]
+    assert np.array_equal(proof.commitments["a"], _g(oracle, a_tau))
+    # z-opening of a(X) alone is not in the proof, but W_zw opens z(X), a, b, d at z w: check the aggregate's
+    # value against the proof's evaluations through the commitment W_zw = [(F_s(tau) - F_s(zw)) / (tau - zw)] G,
+    # with F_s(tau) = z(tau) + aw' a(tau) + aw'^2 b(tau) + aw'^3 d(tau) from the commitments' discrete logs:
+    ev = {k: _ints(oracle, v)[0] for k, v in proof.evaluations.items()}
+    ch = proof.challenges
+    wires_tau = []
+    for j in (0, 1, 3):
+        ctx.fr_ntt_dev(d_wit.ptr + 32 * j * n, n, coeffs.ptr, gk, pa.NTT_INVERSE)
+        wires_tau.append(_ints(oracle, ctx.fr_evaluate(coeffs.ptr, n, _mont(oracle, TAU)))[0])
+    # z(tau) is not recomputed here: solve the KZG equation for it and check it against the commitment to z
+    zw = ch["z"] * B.Domain(n).group_gen % R
+    aws = ch["aw_shifted"]
+    sh_eval = (ev["z_next"] + aws * ev["a_next"] + aws ** 2 * ev["b_next"] + aws ** 3 * ev["d_next"]) % R
+    # [W_zw] (tau - zw) + sh_eval G - sum aws^i [w_i] = [z]   in the exponent, all points known on the CPU side
+    lhs = oracle.g1_add(oracle.g1_mul(proof.commitments["w_zw"], ints_to_limbs([(TAU - zw) % R], 4)[0]),
+                        _g(oracle, sh_eval - sum(pow(aws, i + 1, R) * w for i, w in enumerate(wires_tau))))
+    assert np.array_equal(lhs, proof.commitments["z"])
+    d_wit.free()
+    coeffs.free()
 
 
 def test_wide_circuit_is_satisfied_and_proves(ctx, oracle):
@@ -286,7 +404,8 @@ def test_wide_circuit_is_satisfied_and_proves(ctx, oracle):
     assert sorted(sig.tolist()) == list(range(4 * n)) and (sig != np.arange(4 * n)).sum() > 2 * n
     assert all(w[p] == w[sig[p]] for p in range(4 * n))
     srs = oracle.g1_bases_arith(ints_to_limbs([3], 4)[0], ints_to_limbs([5], 4)[0], n, 4)
-    proof = PR.prove(PR.preprocess(circuit, ctx), pa.CommitKey(srs, ctx), d_wit, None)
+    ck = pa.CommitKey(srs, ctx)
+    proof = PR.prove(PR.preprocess(circuit, ctx, ck), ck, d_wit, None)
     assert PR.check_identity(proof, n, 0)
     assert PR.Proof.from_bytes(proof.to_bytes()).to_bytes() == proof.to_bytes()
 
@@ -299,50 +418,61 @@ def _pt(oracle, xy):
     return (v[0], v[1])
 
 
-@pytest.mark.parametrize("n", [16, 128])
-def test_gpu_proof_passes_the_pairing_verifier(ctx, oracle, n):
-    """End to end without the prover-side oracle: SRS generated on the GPU, proof made on the GPU,
-    challenges re-derived from the proof bytes by replaying the transcript, then the verifier's
-    scalar identity and the KZG pairing equation (oracle/plonk_verifier_oracle.py, plain-Python
+@pytest.mark.parametrize("n,mixed", [(16, False), (32, True), (128, True)])
+def test_gpu_proof_passes_the_pairing_verifier(ctx, oracle, n, mixed):
+    """End to end without the prover-side oracle: SRS generated on the GPU, verifier key and proof made on
+    the GPU, challenges re-derived from the 1040 proof bytes by replaying the transcript over the verifier
+    key, then dusk's verifier: quotient evaluation, linearisation commitment (all five widgets), the two
+    aggregate openings and the batched KZG pairing equation (oracle/plonk_verifier_oracle.py, plain-Python
     pairing).  Tampered proofs must fail."""
     import plonk_prototype_amd as pa
     import plonk_prototype_amd.prover as PR
     from oracle import pairing_oracle as PG
     from oracle import plonk_verifier_oracle as PV
     tau = TAU
-    circuit, wit, pub = pa.synthetic.chain_circuit(n, 77 + n)
+    circuit, wit, pub = _circuit(n, 77 + n, mixed)
     ck = pa.CommitKey.setup(n - 1, _mont(oracle, tau), ctx, precompute=(n > 16))
-    pk = PR.preprocess(circuit, ctx)
-    proof = PR.Proof.from_bytes(PR.prove(pk, ck, wit, pub).to_bytes())        # what a verifier receives
-    ch = PR.derive_challenges(proof, n)
-    vk = {k: _pt(oracle, v) for k, v in PR.verifier_key(pk, ck).items()}
+    pk = PR.preprocess(circuit, ctx, ck)
+    sent = PR.prove(pk, ck, wit, pub)
+    proof = PR.Proof.from_bytes(sent.native_bytes)                             # what a verifier receives: no t(z)
+    vk = {k: _pt(oracle, v) for k, v in pk.verifier_key.items()}
     comms = {k: _pt(oracle, v) for k, v in proof.commitments.items()}
     ev = {k: _ints(oracle, v)[0] for k, v in proof.evaluations.items()}
-    pub_z = B.horner(B.ifft(_ints(oracle, pub), n.bit_length() - 1), ch["z"])
+    assert "t" not in ev and len(ev) == 16
+    # the verifier computes t(z) itself; z does not depend on it, so derive z first
+    ch0 = PR.derive_challenges(proof, pk.verifier_key, n, pub, t_eval=0)
+    pub_z = B.horner(B.ifft(_ints(oracle, pub), n.bit_length() - 1), ch0["z"])
+    t_eval = PV.quotient_evaluation(n, ev, ch0, pub_z)
+    ch = PR.derive_challenges(proof, pk.verifier_key, n, pub, t_eval=t_eval)
     tau_g2 = PG.g2_mul(tau, PG.G2_GEN)
     assert PV.verify(n, vk, comms, ev, ch, pub_z, tau_g2) == (True, True)
     # the prover derived the same challenges
-    assert ch == PR.prove(pk, ck, wit, pub).challenges
-    if n == 16:
+    assert {k: ch[k] for k in sent.challenges} == sent.challenges
+    assert t_eval == _ints(oracle, sent.evaluations["t"])[0]
+    if n <= 32:
         bad = dict(ev, c=(ev["c"] + 1) % R)
-        assert PV.verify(n, vk, comms, bad, ch, pub_z, tau_g2) == (False, False)
+        assert PV.verify(n, vk, comms, bad, ch, pub_z, tau_g2)[1] is False
+        bad = dict(ev, d_next=(ev["d_next"] + 1) % R)
+        assert PV.verify(n, vk, comms, bad, ch, pub_z, tau_g2)[1] is False
         swapped = dict(comms, t_1=comms["t_2"], t_2=comms["t_1"])
         assert PV.verify(n, vk, swapped, ev, ch, pub_z, tau_g2)[1] is False
-        # a proof for a different witness does not verify against tampered public inputs
-        assert PV.verify(n, vk, comms, ev, ch, (pub_z + 1) % R, tau_g2)[0] is False
+        # tampered public inputs: another t(z), the opening of the quotient no longer matches
+        assert PV.verify(n, vk, comms, ev, ch, (pub_z + 1) % R, tau_g2)[1] is False
 
 
-@pytest.mark.parametrize("log_n", [10, 14])
-def test_prove_matches_the_c_prover(ctx, oracle, log_n):
+@pytest.mark.parametrize("log_n,mixed", [(10, False), (10, True), (14, True)])
+def test_prove_matches_the_c_prover(ctx, oracle, log_n, mixed):
     """Sizes beyond the big-int oracle: every commitment and evaluation of the GPU proof equals the
     CPU prover composed from the C restatement (oracle/cpu_prover.py), same challenges."""
     import plonk_prototype_amd as pa
     import plonk_prototype_amd.prover as PR
     from oracle import cpu_prover as CP
     n = 1 << log_n
-    circuit, wit, pub = pa.synthetic.chain_circuit(n, 100 + log_n)
+    circuit, wit, pub = _circuit(n, 100 + log_n, mixed)
     srs = oracle.g1_bases_arith(ints_to_limbs([0xA5A5], 4)[0], ints_to_limbs([0x7FFFFFFF], 4)[0], n, 8)
-    proof = PR.prove(PR.preprocess(circuit, ctx), pa.CommitKey(srs, ctx, precompute=True), wit, pub)
+    ck = pa.CommitKey(srs, ctx, precompute=True)
+    pk = PR.preprocess(circuit, ctx, ck)
+    proof = PR.prove(pk, ck, wit, pub)
     cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
     exp = CP.prove(oracle, cpk, srs, wit, pub, proof.challenges, threads=8)
     assert set(exp["commitments"]) == set(proof.commitments) and set(exp["evaluations"]) == set(proof.evaluations)
@@ -350,6 +480,8 @@ def test_prove_matches_the_c_prover(ctx, oracle, log_n):
         assert np.array_equal(proof.evaluations[k], v), k
     for k, v in exp["commitments"].items():
         assert np.array_equal(proof.commitments[k], v), k
+    for k, v in CP.verifier_key(oracle, cpk, srs, threads=8).items():
+        assert np.array_equal(pk.verifier_key[k], v), k
 
 
 def test_round_kernels_empty_and_bad_arguments(ctx, oracle):
@@ -384,43 +516,3 @@ def test_round_kernels_empty_and_bad_arguments(ctx, oracle):
     out = C.c_void_p()
     assert lib.pm_g1_bases_from_dev(h, None, 0, C.byref(out)) == 0 and lib.pm_g1_bases_len(out) == 0
     lib.pm_g1_bases_free(h, out)
-
-
-@pytest.mark.parametrize("n,with_pi", [(4, True), (64, True), (1024, False), (1 << 14, True)])
-def test_native_prover_equals_the_python_sequence(ctx, oracle, n, with_pi):
-    """pm_plonk_prove (rounds and Merlin transcript in C++ inside the library) must return the very
-    proof prover.prove() returns -- commitments, evaluations and challenges."""
-    import plonk_prototype_amd as pa
-    import plonk_prototype_amd.prover as PR
-    circuit, wit, pub = pa.synthetic.chain_circuit(n, 500 + n)
-    srs = oracle.g1_bases_arith(ints_to_limbs([0xBEEF], 4)[0], ints_to_limbs([0x10000001], 4)[0], n, 8)
-    ck = pa.CommitKey(srs, ctx, precompute=(n >= 64))
-    d_wit = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
-    d_pub = pa.DeviceVector.from_host(ctx, pub) if with_pi else None
-    ref = PR.prove(PR.preprocess(circuit, ctx), ck, d_wit, d_pub)
-    npk = PR.NativeProverKey(circuit, ctx)
-    got = PR.prove_native(npk, ck, d_wit, d_pub)
-    assert got.challenges == ref.challenges
-    assert got.to_bytes() == ref.to_bytes()
-    again = PR.prove_native(npk, ck, d_wit, d_pub)                  # workspace reuse
-    assert again.to_bytes() == ref.to_bytes()
-    other = PR.prove_native(npk, ck, d_wit, d_pub, label=b"another protocol")
-    assert other.challenges["beta"] != ref.challenges["beta"]
-    npk.free()
-
-
-def test_native_prover_rejects_bad_input(ctx, oracle):
-    import ctypes as C
-    import plonk_prototype_amd as pa
-    import plonk_prototype_amd.prover as PR
-    circuit, wit, pub = pa.synthetic.chain_circuit(16, 3)
-    bad = PR.Circuit(**{**circuit.__dict__, "sigma_index": circuit.sigma_index.copy()})
-    bad.sigma_index[0, 0] = bad.sigma_index[0, 1]
-    with pytest.raises(pa.Error):
-        PR.NativeProverKey(bad, ctx)
-    npk = PR.NativeProverKey(circuit, ctx)
-    short = pa.CommitKey(oracle.g1_bases_arith(ints_to_limbs([1], 4)[0], ints_to_limbs([1], 4)[0], 8, 1), ctx)
-    with pytest.raises(pa.Error) as e:
-        PR.prove_native(npk, short, pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4)))
-    assert e.value.code == -6
-    npk.free()

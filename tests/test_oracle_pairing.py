@@ -46,30 +46,32 @@ def _commit(coeffs, tau):
 
 def test_verifier_accepts_oracle_proofs_and_rejects_tampering():
     from plonk_prototype_amd.field import fr_vec_from_limbs
-    from plonk_prototype_amd.synthetic import chain_circuit
-    n, tau = 8, 0xABCDEF0123456789 ** 3 % R
-    c, w, pi = chain_circuit(n, 6)
-    sel = {k: fr_vec_from_limbs(getattr(c, k)) for k in ("q_m", "q_l", "q_r", "q_o", "q_4", "q_c")}
+    from plonk_prototype_amd.synthetic import mixed_circuit
+    n, tau = 32, 0xABCDEF0123456789 ** 3 % R
+    c, w, pi = mixed_circuit(n, 6)                    # every gate kind: all five widgets enter [r]
+    sel = {k: fr_vec_from_limbs(getattr(c, k)) for k in PO.SELECTORS}
     sigma, wit, pii = c.sigma_index.tolist(), [fr_vec_from_limbs(w[j]) for j in range(4)], fr_vec_from_limbs(pi)
-    ch = {"beta": 11 ** 20 % R, "gamma": 13 ** 21 % R, "alpha": 17 ** 19 % R, "z": 19 ** 23 % R, "v": 23 ** 17 % R,
-          "u": 29 ** 15 % R}
+    ch = {k: pow(11 + 2 * i, 20 + i, R) for i, k in enumerate(PO.CHALLENGES + ("batch",))}
     out = PO.prove(n, sel, sigma, wit, pii, ch)
-    dom = B.Domain(n)
-    roots = PO.powers(dom.group_gen, 1, n)
-    table = [PO.K[j] * roots[i] % R for j in range(4) for i in range(n)]
-    vk = {k: _commit(B.ifft(v, 3), tau) for k, v in sel.items()}
+    vk = {k: _commit(out["sel_coeffs"][k], tau) for k in PO.SELECTORS}
     for j in range(4):
-        vk[f"sigma_{j + 1}"] = _commit(B.ifft([table[p] for p in sigma[j]], 3), tau)
+        vk[f"sigma_{j + 1}"] = _commit(out["sigma_coeffs"][j], tau)
     comms = {nm: _commit(out["wire_coeffs"][j], tau) for j, nm in enumerate("abcd")}
     comms["z"] = _commit(out["z_coeffs"], tau)
     for i in range(4):
         comms[f"t_{i + 1}"] = _commit(out["t_coeffs"][i * n:(i + 1) * n], tau)
     comms["w_z"], comms["w_zw"] = _commit(out["w_z"], tau), _commit(out["w_zw"], tau)
-    pi_z = B.horner(B.ifft(pii, 3), ch["z"])
+    pi_z = B.horner(B.ifft(pii, 5), ch["z"])
     tau_g2 = PG.g2_mul(tau, PG.G2_GEN)
     assert PV.verify(n, vk, comms, out["evals"], ch, pi_z, tau_g2) == (True, True)
     bad_ev = dict(out["evals"], a=(out["evals"]["a"] + 1) % R)
     assert PV.verify(n, vk, comms, bad_ev, ch, pi_z, tau_g2) == (False, False)
+    for name in ("a_next", "b_next", "d_next", "q_arith", "q_c", "q_l", "q_r"):      # the openings dusk's Proof adds
+        bad_ev = {k: v for k, v in out["evals"].items() if k != "t"}
+        bad_ev[name] = (bad_ev[name] + 1) % R
+        assert PV.verify(n, vk, comms, bad_ev, ch, pi_z, tau_g2)[1] is False, name
     bad_c = dict(comms, w_z=B.g1_add(comms["w_z"], B.G1_GEN))
     assert PV.verify(n, vk, bad_c, out["evals"], ch, pi_z, tau_g2) == (True, False)
+    bad_vk = dict(vk, q_logic=B.g1_add(vk["q_logic"], B.G1_GEN))
+    assert PV.verify(n, bad_vk, comms, out["evals"], ch, pi_z, tau_g2) == (True, False)
     assert PV.verify(n, vk, comms, out["evals"], ch, (pi_z + 1) % R, tau_g2)[0] is False

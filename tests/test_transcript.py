@@ -97,7 +97,7 @@ def test_proof_serialisation_roundtrip(oracle):
     for i, k in enumerate(Proof.EVALUATIONS):
         p.evaluations[k] = fr_to_limbs((i + 1) * 0x123456789ABCDEF % R_MOD)
     blob = p.to_bytes()
-    assert len(blob) == 11 * 48 + 10 * 32
+    assert len(blob) == 11 * 48 + 16 * 32 == 1040
     q = Proof.from_bytes(blob)
     assert all(np.array_equal(q.commitments[k], p.commitments[k]) for k in Proof.COMMITMENTS)
     assert all(np.array_equal(q.evaluations[k], p.evaluations[k]) for k in Proof.EVALUATIONS)
