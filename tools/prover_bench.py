@@ -30,13 +30,13 @@ srs = orc.g1_bases_arith(k0, d, n, threads=16)
 print(f"srs stand-in: {time.time() - t0:.1f}s host", flush=True)
 ck = pa.CommitKey(srs, ctx, precompute=True)
 t0 = time.time()
-pk = pa.preprocess(circuit, ctx)
+pk = pa.preprocess(circuit, ctx, ck)
 ctx.sync()
 print(f"preprocess: {time.time() - t0:.3f}s", flush=True)
 if not wide:
     dw = pa.DeviceVector.from_host(ctx, wit.reshape(-1, 4))
 del circuit
-dpi = pa.DeviceVector.from_host(ctx, pi)
+dpi = pa.prover.sparse_public_inputs(pi)
 proof = pa.prove(pk, ck, dw, dpi)
 pi_z = 0 if wide else pa.field.fr_from_limbs(orc.fr_poly_evaluate(orc.fr_ntt(pi, log_n, 1, threads=16),
                                                                   pa.field.fr_to_limbs(proof.challenges["z"])))
