@@ -227,6 +227,10 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_ntt_pipeline = value != 0;
     return PM_OK;
   }
+  if (!strcmp(key, "ntt_direct_tw")) {
+    ctx->opt_ntt_direct_tw = value != 0;
+    return PM_OK;
+  }
   if (!strcmp(key, "ntt_radix")) {
     if (value != 4 && value != 8) return set_err(ctx, PM_ERR_BAD_ARG, "ntt_radix must be 4 or 8");
     ctx->opt_ntt_radix = value;

@@ -86,6 +86,7 @@ struct pm_ctx {
   long opt_ntt_xcd = 1;          // XCD-aware blockIdx -> tile mapping
   long opt_ntt_pipeline = 1;     // host-pointer batch calls: overlap H2D / transform / D2H per vector
   long opt_ntt_max_radix = 10;   // log2 of the largest pass radix (multi-pass plans)
+  long opt_ntt_direct_tw = 1;    // inter-pass twiddles from per-pass N x 36 B tables (1) or from the two-level tables + one product (0)
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
   int num_cus = 256;

@@ -300,7 +300,7 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
   const u32 pre = (coset && !dir) ? PASS_PRE_COSET : 0u;
   // n^-1 of an inverse transform: folded into the last pass's twiddle table when there are two
   // or more passes with direct tables; otherwise multiplied explicitly (PASS_POST_SCALE)
-  const bool direct_tw = log_n <= 26;  // tables of N x 36 B per twiddled pass and direction
+  const bool direct_tw = log_n <= 26 && ctx->opt_ntt_direct_tw;  // tables of N x 36 B per twiddled pass and direction
 
   Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix);
   const bool scale_folded = dir && plan.npass > 1 && direct_tw;
@@ -438,7 +438,7 @@ extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
       rc = r4 ? get_step4_table(ctx, dir, (unsigned)plan.S[i], &stw, ctx->stream)
               : get_step_table(ctx, dir, (unsigned)plan.S[i], &stw, ctx->stream);
       if (rc) return rc;
-      if (i > 0 && log_n <= 26) {
+      if (i > 0 && log_n <= 26 && ctx->opt_ntt_direct_tw) {
         void* ptw;
         rc = get_pass_tw(ctx, dt, i, last, dir, log_n, log_ns, plan.S[i], wide_glog, kc, ctx->stream, &ptw);
         if (rc) return rc;
