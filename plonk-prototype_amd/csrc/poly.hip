@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "context.h"
 #include "host_field.h"
@@ -98,106 +99,323 @@ __global__ void __launch_bounds__(256) poly_eval_final_kernel(const u32x4* parti
   if (t == 0) st_canon(out, blockIdx.x, acc);
 }
 
-// ------------------------------------------------------------------ Ruffini
-// q_{i-1} = c_i + z q_i.  With k = n-1-i, d_k = c_{n-1-k}: y_k = d_k + z y_{k-1} = z^k sum_{s<=k} d_s z^-s,
-// so the recurrence becomes an element-wise scaling, a prefix SUM, and a scaling back.
-struct ScanArgs {
-  const u32x4* coeffs;   // canonical, n
-  u32x4* tmp;            // canonical, n-1: block-local inclusive prefix sums of d_s z^-s
-  u32x4* block_tot;      // 48-byte entries, one per block
-  const u32x4* zi_hi;    // z^-(x << lh), 48-byte entries
-  const u32x4* zi_lo;    // z^-x
-  const u32x4* z_hi;     // z^(x << lh)
-  const u32x4* z_lo;
-  u32x4* out;            // canonical, n-1
-  size_t n;              // coefficients
-  u32 lh;
-  u32 L;                 // tiles of 256 per block
-};
+// ------------------------------------------------------------------ chunked scans (prefix product, Ruffini)
+// Both are first-order recurrences y_k = op(a_k, y_{k-1}) over the whole vector:
+//   prefix product   out_k = y_{k-1},  y_k = y_{k-1} a_k           (the grand product z of the permutation argument)
+//   Ruffini          y_k = d_k + z y_{k-1},  out = y_k             (q_{i-1} = c_i + z q_i read from the top coefficient down)
+// and both are computed the same way (r02; replaces the LDS-staged three-kernel scans of r01, which moved
+// 160 B and ~5 products per element):
+//   totals  every thread runs the recurrence over its SC_K consecutive elements from the neutral start and
+//           keeps only the chunk's total: 1 product per element, n / SC_K values written
+//   scan    the totals obey the SAME recurrence one level up (Ruffini: with z^SC_K in place of z): recurse
+//           until one workgroup holds the level (<= SC_BASE entries) and scans it in place
+//   replay  every thread runs the recurrence again from its chunk's carry and writes the outputs:
+//           1 product per element
+// ~2.2 products and 32 + 32 + 32 B (the second read mostly from the Infinity Cache) per element.
+constexpr int SC_K = 8;             // elements per thread
+constexpr int SC_BASE = 2048;       // largest level one workgroup (256 threads x SC_K) scans
+// Level 0 moves whole tiles of 256 x SC_K canonical elements between HBM and the threads' consecutive
+// chunks through LDS: coalesced 16-byte accesses on the HBM side (all of a tile's loads in flight at once),
+// one padding slot per chunk on the LDS side (lane stride 17 x 16 B: conflict-free ds_read/write_b128).
 PM_DEV Fr fr_shfl_up(const Fr& v, int d) {
   Fr r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = __shfl_up(v.l[i], d);
   return r;
 }
-// inclusive prefix sum across the 256 threads of a block (values (1, <1.01) in, same out)
-PM_DEV Fr block_scan_256(Fr v, u32* sh /* 4 * 9 words */) {
+// ABI (canonical) -> device form without a product: x 2^5, then the one-limb reduction
+PM_DEV Fr abi_to_dev(const Fr& x) { return fe_reduce_weak<FrP>(fr_shl5(x)); }
+
+constexpr int SC_TILE = 256 * SC_K;
+constexpr int SC_H = 2;                               // a tile passes through LDS in SC_H rounds of SC_K / SC_H elements per thread
+constexpr int SC_R = SC_K / SC_H;                     // elements per thread and round
+constexpr int SC_LDS_SLOTS = 256 * (2 * SC_R + 1);   // 16-byte slots: 36 KB -> four workgroups per CU
+// `rev`: element e of the tile lives at in[first - e] instead of in[first + e] (Ruffini walks the coefficients down).
+// Round h moves elements {chunk * SC_K + h * SC_R + r}: per wave 128-byte runs (whole cache lines) every 256 bytes.
+PM_DEV void tile_load(const u32x4* in, long long first, bool rev, long long n_valid /* elements e < n_valid exist */,
+                      u32x4* lds, u32 (&w)[SC_K][8]) {
+  const u32 t = threadIdx.x;
+#pragma unroll
+  for (int h = 0; h < SC_H; ++h) {
+    u32x4 v[2 * SC_R];
+#pragma unroll
+    for (int i = 0; i < 2 * SC_R; ++i) {
+      const u32 g = i * 256 + t;                                  // piece index of this round, memory order (or its mirror)
+      const u32 gm = rev ? (u32)(256 * 2 * SC_R - 1) - g : g;     // rev: the mirrored piece, so that addresses still ascend with g
+      const u32 chunk = gm / (2 * SC_R), within = gm % (2 * SC_R);
+      const u32 piece = rev ? (within ^ 1u) : within;             // 2 * element + half, inside the thread's chunk
+      const u32 e = chunk * SC_K + h * SC_R + (piece >> 1), half = piece & 1u;
+      v[i] = u32x4{0u, 0u, 0u, 0u};
+      if ((long long)e < n_valid) v[i] = in[2 * (rev ? first - (long long)e : first + (long long)e) + half];
+    }
+    if (h > 0) __syncthreads();                                   // the previous round's reads are done
+#pragma unroll
+    for (int i = 0; i < 2 * SC_R; ++i) {
+      const u32 g = i * 256 + t;
+      const u32 gm = rev ? (u32)(256 * 2 * SC_R - 1) - g : g;
+      const u32 chunk = gm / (2 * SC_R), within = gm % (2 * SC_R);
+      const u32 piece = rev ? (within ^ 1u) : within;             // slot order inside a chunk: element-major, low half first
+      lds[chunk * (2 * SC_R + 1) + piece] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SC_R; ++r) {
+      const u32x4 a = lds[t * (2 * SC_R + 1) + 2 * r], b = lds[t * (2 * SC_R + 1) + 2 * r + 1];
+      const int k = h * SC_R + r;
+      w[k][0] = a.x; w[k][1] = a.y; w[k][2] = a.z; w[k][3] = a.w;
+      w[k][4] = b.x; w[k][5] = b.y; w[k][6] = b.z; w[k][7] = b.w;
+    }
+  }
+  __syncthreads();
+}
+PM_DEV void tile_store(u32x4* out, long long first, bool rev, long long n_valid, u32x4* lds, const u32 (&w)[SC_K][8]) {
+  const u32 t = threadIdx.x;
+#pragma unroll
+  for (int h = 0; h < SC_H; ++h) {
+    if (h > 0) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SC_R; ++r) {
+      const int k = h * SC_R + r;
+      lds[t * (2 * SC_R + 1) + 2 * r] = u32x4{w[k][0], w[k][1], w[k][2], w[k][3]};
+      lds[t * (2 * SC_R + 1) + 2 * r + 1] = u32x4{w[k][4], w[k][5], w[k][6], w[k][7]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2 * SC_R; ++i) {
+      const u32 g = i * 256 + t;
+      const u32 gm = rev ? (u32)(256 * 2 * SC_R - 1) - g : g;
+      const u32 chunk = gm / (2 * SC_R), within = gm % (2 * SC_R);
+      const u32 piece = rev ? (within ^ 1u) : within;
+      const u32 e = chunk * SC_K + h * SC_R + (piece >> 1), half = piece & 1u;
+      if ((long long)e < n_valid) out[2 * (rev ? first - (long long)e : first + (long long)e) + half] = lds[chunk * (2 * SC_R + 1) + piece];
+    }
+  }
+}
+
+// ---- prefix product.  Level 0 reads canonical ABI elements tile-wise; inner levels hold device-form 48-byte
+// entries (1 / SC_K of the data each) and use plain per-thread loops.
+__global__ void __launch_bounds__(256) pp_totals0_kernel(const u32x4* in, size_t n, u32x4* tot) {
+  extern __shared__ u32x4 sc_lds[];
+  const size_t tile0 = (size_t)blockIdx.x * SC_TILE;
+  u32 w[SC_K][8];
+  tile_load(in, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
+  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x, lo = chunk * SC_K;
+  if (lo >= n) return;
+  Fr acc = abi_to_dev(fe_unpack<FrP>(w[0]));
+#pragma unroll
+  for (int k = 1; k < SC_K; ++k)
+    if (lo + k < n) acc = fe_mul<FrP>(acc, abi_to_dev(fe_unpack<FrP>(w[k])));
+  st_tw(tot, chunk, acc);
+}
+// carry[chunk] = product of everything before the chunk (device form); out_e = that product in ABI form
+__global__ void __launch_bounds__(256) pp_replay0_kernel(const u32x4* in, size_t n, const u32x4* carry, u32x4* out) {
+  extern __shared__ u32x4 sc_lds[];
+  const size_t tile0 = (size_t)blockIdx.x * SC_TILE;
+  u32 w[SC_K][8];
+  tile_load(in, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
+  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x, lo = chunk * SC_K;
+  if (lo < n) {
+    Fr run = fe_mul<FrP>(ld_tw(carry, chunk), fe_pow2<FrP, 256>());   // device form -> ABI form; ABI x device stays ABI
+#pragma unroll
+    for (int k = 0; k < SC_K; ++k) {
+      const Fr a = abi_to_dev(fe_unpack<FrP>(w[k]));
+      fe_canon_pack<FrP>(w[k], run);
+      run = fe_mul<FrP>(run, a);
+    }
+  }
+  tile_store(out, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
+}
+__global__ void __launch_bounds__(256) pp_totals_kernel(const u32x4* in, size_t n, u32x4* tot, size_t nchunks) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nchunks) return;
+  const size_t lo = t * SC_K;
+  Fr a[SC_K];
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) a[k] = lo + k < n ? ld_tw(in, lo + k) : fe_one<FrP>();   // all loads in flight at once
+  Fr acc = a[0];
+#pragma unroll
+  for (int k = 1; k < SC_K; ++k) acc = fe_mul<FrP>(acc, a[k]);
+  st_tw(tot, t, acc);
+}
+__global__ void __launch_bounds__(256) pp_replay_kernel(const u32x4* in, size_t n, const u32x4* carry, size_t nchunks,
+                                                         u32x4* out) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nchunks) return;
+  const size_t lo = t * SC_K;
+  Fr a[SC_K];
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) a[k] = lo + k < n ? ld_tw(in, lo + k) : fe_one<FrP>();   // read before the slots are overwritten
+  Fr run = ld_tw(carry, t);
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    if (lo + k < n) st_tw(out, lo + k, run);
+    run = fe_mul<FrP>(run, a[k]);
+  }
+}
+// one workgroup, m <= SC_BASE device-form entries, exclusive product scan in place
+__global__ void __launch_bounds__(256) pp_base_kernel(u32x4* v, u32 m) {
+  __shared__ u32 sh[4 * 9];
   const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const Fr one = fe_one<FrP>();
+  const u32 lo = t * SC_K, hi = lo + SC_K < m ? lo + SC_K : m;
+  Fr tot = one;
+  for (u32 e = lo; e < hi; ++e) tot = fe_mul<FrP>(tot, ld_tw(v, e));
+  Fr incl = tot;
   for (int d = 1; d < 64; d <<= 1) {
-    Fr o = fr_shfl_up(v, d);
-    if (lane >= (u32)d) v = fe_reduce_weak<FrP>(fe_add<FrP>(v, o));
+    const Fr o = fr_shfl_up(incl, d);
+    if (lane >= (u32)d) incl = fe_mul<FrP>(incl, o);
   }
   if (lane == 63) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = v.l[i];
+    for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = incl.l[i];
   }
+  Fr run = fr_shfl_up(incl, 1);
+  if (lane == 0) run = one;
   __syncthreads();
-  Fr carry = fe_zero<FrP>();
   for (u32 w = 0; w < wave; ++w) {
     Fr o;
 #pragma unroll
     for (int i = 0; i < 9; ++i) o.l[i] = sh[w * 9 + i];
-    carry = fe_add<FrP>(carry, o);                       // <= (3, <3.1)
+    run = fe_mul<FrP>(run, o);
   }
-  v = fe_reduce_weak<FrP>(fe_add<FrP>(v, carry));
+  for (u32 e = lo; e < hi; ++e) {
+    const Fr a = ld_tw(v, e);
+    st_tw(v, e, run);
+    run = fe_mul<FrP>(run, a);
+  }
+}
+
+// ---- Ruffini.  Level 0 reads the coefficients top down: d_k = c_{n-1-k}, k < m = n - 1, and writes
+// out[m-1-k] = y_k; inner levels hold ABI-form 48-byte entries (lazily reduced) and are scanned in place.
+// y = d + z y: ABI + device x ABI stays ABI form, value < 3 r, limbs < 2^30.
+struct RufLevel {
+  u32 z[9];       // this level's multiplier z^(SC_K^level), device form
+};
+// level 0: tile over k in [tile0, tile0 + SC_TILE), element k = coefficient n_coeffs - 1 - k (walked downwards)
+__global__ void __launch_bounds__(256) ruf_totals0_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, u32x4* tot,
+                                                           const RufLevel lv) {
+  extern __shared__ u32x4 sc_lds[];
+  const size_t tile0 = (size_t)blockIdx.x * SC_TILE;
+  u32 w[SC_K][8];
+  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x, lo = chunk * SC_K;
+  if (lo >= m) return;
+  const Fr z = fr_limbs(lv.z);
+  Fr y = fe_zero<FrP>();
+  // a short last chunk is padded at the END with zeros: y -> z y, so that every chunk spans exactly SC_K steps
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    y = fe_mul<FrP>(y, z);
+    if (lo + k < m) y = fe_add<FrP>(y, fe_unpack<FrP>(w[k]));
+  }
+  st_tw(tot, chunk, fe_reduce_weak<FrP>(y));
+}
+// carry[chunk] = y just before the chunk; out[m - 1 - k] = y_k, canonical
+__global__ void __launch_bounds__(256) ruf_replay0_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, const u32x4* carry,
+                                                           u32x4* out, const RufLevel lv) {
+  extern __shared__ u32x4 sc_lds[];
+  const size_t tile0 = (size_t)blockIdx.x * SC_TILE;
+  u32 w[SC_K][8];
+  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x, lo = chunk * SC_K;
+  if (lo < m) {
+    const Fr z = fr_limbs(lv.z);
+    Fr y = ld_tw(carry, chunk);
+#pragma unroll
+    for (int k = 0; k < SC_K; ++k) {
+      if (lo + k < m) {
+        y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), fe_unpack<FrP>(w[k])));
+        fe_canon_pack<FrP>(w[k], y);
+      }
+    }
+  }
+  tile_store(out, (long long)(m - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+}
+// inner levels: ABI-form 48-byte entries, scanned in place
+__global__ void __launch_bounds__(256) ruf_totals_kernel(const u32x4* in, size_t m, u32x4* tot, size_t nchunks,
+                                                          const RufLevel lv) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nchunks) return;
+  const Fr z = fr_limbs(lv.z);
+  const size_t lo = t * SC_K;
+  Fr a[SC_K];
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) a[k] = lo + k < m ? ld_tw(in, lo + k) : fe_zero<FrP>();
+  Fr y = fe_zero<FrP>();
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) y = fe_add<FrP>(fe_mul<FrP>(y, z), a[k]);
+  st_tw(tot, t, fe_reduce_weak<FrP>(y));
+}
+// carry[t] = y just before chunk t of this level; every entry k is replaced by the carry INTO it (y_{k-1}): that is
+// what the level below replays from
+__global__ void __launch_bounds__(256) ruf_replay_kernel(u32x4* v, size_t m, const u32x4* carry, size_t nchunks,
+                                                          const RufLevel lv) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nchunks) return;
+  const Fr z = fr_limbs(lv.z);
+  const size_t lo = t * SC_K;
+  Fr a[SC_K];
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) a[k] = lo + k < m ? ld_tw(v, lo + k) : fe_zero<FrP>();
+  Fr y = ld_tw(carry, t);
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    if (lo + k < m) st_tw(v, lo + k, y);
+    y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), a[k]));
+  }
+}
+// one workgroup, m <= SC_BASE entries T_k (ABI form): in place T_k <- y_{k-1} (the carry INTO chunk k), where
+// y_k = T_k + z y_{k-1}, y_{-1} = 0.
+__global__ void __launch_bounds__(256) ruf_base_kernel(u32x4* v, u32 m, const RufLevel lv) {
+  __shared__ u32 sh[4 * 9];
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const Fr z = fr_limbs(lv.z);
+  const u32 lo = t * SC_K;
+  Fr y = fe_zero<FrP>();
+  for (u32 k = lo; k < lo + SC_K; ++k) {     // padded like the totals: every thread spans SC_K steps
+    y = fe_mul<FrP>(y, z);
+    if (k < m) y = fe_add<FrP>(y, ld_tw(v, k));
+  }
+  y = fe_reduce_weak<FrP>(y);
+  // inclusive scan over the threads: Y_t = y_t + z^(SC_K) Y_{t-1}; the multiplier of a step of d threads is z^(SC_K d)
+  Fr zp = z;
+  for (int i = 1; i < SC_K; i <<= 1) zp = fe_mul<FrP>(zp, zp);   // z^SC_K (SC_K is a power of two)
+  Fr incl = y;
+  for (int d = 1; d < 64; d <<= 1) {
+    const Fr o = fr_shfl_up(incl, d);
+    if (lane >= (u32)d) incl = fe_reduce_weak<FrP>(fe_add<FrP>(incl, fe_mul<FrP>(o, zp)));
+    zp = fe_mul<FrP>(zp, zp);
+  }
+  // zp = z^(SC_K 64): one wave's span
+  if (lane == 63) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = incl.l[i];
+  }
+  Fr carry = fr_shfl_up(incl, 1);            // y before this thread, inside the wave
+  if (lane == 0) carry = fe_zero<FrP>();
   __syncthreads();
-  return v;
-}
-__global__ void __launch_bounds__(256) ruffini_local_kernel(const ScanArgs a) {
-  __shared__ u32 sh[4 * 9 + 9];
-  const u32 t = threadIdx.x, b = blockIdx.x;
-  const size_t m = a.n - 1;  // outputs
-  Fr run = fe_zero<FrP>();   // sum of the earlier tiles of this block
-  for (u32 j = 0; j < a.L; ++j) {
-    const size_t k = ((size_t)b * a.L + j) * 256 + t;
-    Fr e = fe_zero<FrP>();
-    if (k < m) e = fe_mul<FrP>(ld_canon(a.coeffs, a.n - 1 - k), two_level(a.zi_hi, a.zi_lo, (u32)k, a.lh));
-    e = fe_reduce_weak<FrP>(e);
-    Fr s = block_scan_256(e, sh);
-    s = fe_reduce_weak<FrP>(fe_add<FrP>(s, run));
-    if (k < m) st_canon(a.tmp, k, s);
-    if (t == 255) {
+  // what enters this wave: W = sum over earlier waves; then it reaches lane l multiplied by z^(SC_K l)
+  Fr wcar = fe_zero<FrP>();
+  for (u32 w = 0; w < wave; ++w) {
+    Fr o;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) sh[36 + i] = s.l[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 9; ++i) run.l[i] = sh[36 + i];
-    __syncthreads();
+    for (int i = 0; i < 9; ++i) o.l[i] = sh[w * 9 + i];
+    wcar = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(wcar, zp), o));
   }
-  if (t == 0) st_tw(a.block_tot, b, run);
-}
-// exclusive prefix sum of the block totals (one block; serial over groups of 256)
-__global__ void __launch_bounds__(256) ruffini_carry_kernel(u32x4* block_tot, u32 nblocks) {
-  __shared__ u32 sh[4 * 9 + 9];
-  const u32 t = threadIdx.x;
-  Fr run = fe_zero<FrP>();
-  for (u32 base = 0; base < nblocks; base += 256) {
-    const u32 i = base + t;
-    Fr v = i < nblocks ? ld_tw(block_tot, i) : fe_zero<FrP>();
-    Fr s = block_scan_256(v, sh);                         // inclusive
-    Fr incl = fe_reduce_weak<FrP>(fe_add<FrP>(s, run));
-    // exclusive value for block i = inclusive - own = run + (s - v): recompute as run + scan of the others
-    Fr excl = fe_reduce_weak<FrP>(fe_sub<FrP, 3, 1>(incl, v));
-    if (i < nblocks) st_tw(block_tot, i, excl);
-    if (t == 255) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sh[36 + k] = incl.l[k];
+  if (wave > 0) {
+    Fr zl = fe_one<FrP>(), b = z;              // z^(SC_K lane) by square-and-multiply on (SC_K lane)
+    for (u32 e = SC_K * lane; e; e >>= 1) {
+      if (e & 1) zl = fe_mul<FrP>(zl, b);
+      b = fe_mul<FrP>(b, b);
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 9; ++k) run.l[k] = sh[36 + k];
-    __syncthreads();
+    carry = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(wcar, zl)));
   }
-}
-__global__ void __launch_bounds__(256) ruffini_final_kernel(const ScanArgs a) {
-  const size_t m = a.n - 1;
-  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= m) return;
-  const size_t b = k / ((size_t)256 * a.L);
-  Fr s = fe_add<FrP>(ld_canon(a.tmp, k), ld_tw(a.block_tot, b));              // (2, <2.1)
-  Fr y = fe_mul<FrP>(s, two_level(a.z_hi, a.z_lo, (u32)k, a.lh));              // * z^k
-  st_canon(a.out, m - 1 - k, fe_reduce_weak<FrP>(y));                          // q_{n-2-k}
+  y = carry;
+  for (u32 k = lo; k < lo + SC_K && k < m; ++k) {
+    const Fr a = ld_tw(v, k);
+    st_tw(v, k, y);
+    y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), a));
+  }
 }
 // z == 0: q_{i-1} = c_i
 __global__ void ruffini_shift_kernel(const u32x4* coeffs, u32x4* out, size_t m) {
@@ -209,177 +427,67 @@ __global__ void ruffini_shift_kernel(const u32x4* coeffs, u32x4* out, size_t m) 
 
 // ------------------------------------------------------------------ batch inversion
 // Montgomery's trick per thread over `L` elements taken with stride T (coalesced), one Fermat
-// inversion per thread.  Works in the device Montgomery domain: u = a * 2^5 (ABI -> device form),
-// prefix products in device form, inverse in device form, result shifted back to ABI form.
+// inversion per thread.  Forms: u = a * 2^5 (ABI -> device form, a shift and a weak reduction, no
+// product); prefix products in device form; the inverse of the thread's product is moved to ABI form
+// once, after which inverse(ABI) x prefix(device) and inverse(ABI) x u(device) both stay in ABI form:
+// 3 products per element (r01: 6) + ~325 per thread for x^(r-2) with 4-bit windows and dedicated
+// squarings (r01: 380 general products).  The floor is the serial exponentiation: one thread's ~325
+// dependent products are ~0.15 ms however the elements are distributed.
 __global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, size_t n, u32 L, u32x4* scratch) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const Fr one = fe_one<FrP>();
-  const Fr to_dev = fe_pow2<FrP, 2 * 261 - 256>();   // a * this / 2^261 = a * 2^5
-  const Fr to_abi = fe_pow2<FrP, 256>();             // d * this / 2^261 = d / 2^5
   Fr acc = one;
   for (u32 j = 0; j < L; ++j) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) break;
-    Fr a = fe_mul<FrP>(ld_canon(v, i), to_dev);
-    u32 s[8];
-    fe_canon_pack<FrP>(s, a);
+    const Fr raw = ld_canon(v, i);
     u32 nz = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) nz |= s[q];
+    for (int q = 0; q < 9; ++q) nz |= raw.l[q];
     st_tw(scratch, i, acc);                    // product of the earlier non-zero elements
-    if (nz) acc = fe_mul<FrP>(acc, a);
+    if (nz) acc = fe_mul<FrP>(acc, abi_to_dev(raw));
   }
-  // acc^(r-2)
-  Fr inv = one, base = acc;
+  // acc^(r-2), 4-bit fixed windows from the top: 252 squarings + 63 table products + 14 to build the table
+  Fr inv;
   {
+    Fr tab[16];
+    tab[0] = one;
+    tab[1] = acc;
+#pragma unroll
+    for (int i = 2; i < 16; ++i) tab[i] = fe_mul<FrP>(tab[i - 1], acc);
     constexpr u32 E[8] = {0xffffffffu, 0xfffffffeu, 0xfffe5bfeu, 0x53bda402u,
                           0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};  // r - 2
-    for (int w = 0; w < 8; ++w) {
-      for (int bit = 0; bit < 32; ++bit) {
-        if ((E[w] >> bit) & 1) inv = fe_mul<FrP>(inv, base);
-        base = fe_mul<FrP>(base, base);
+    inv = one;
+    for (int w = 7; w >= 0; --w) {
+      for (int nib = 7; nib >= 0; --nib) {
+        if (!(w == 7 && nib == 7)) {
+          inv = fe_sqr<FrP>(inv); inv = fe_sqr<FrP>(inv); inv = fe_sqr<FrP>(inv); inv = fe_sqr<FrP>(inv);
+        }
+        const u32 d = (E[w] >> (4 * nib)) & 15u;
+        // a table in registers indexed by a runtime value would spill: select with a compare chain
+        Fr m = tab[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) m.l[q] = d == (u32)i ? tab[i].l[q] : m.l[q];
+        }
+        if (d) inv = fe_mul<FrP>(inv, m);
       }
     }
   }
+  inv = fe_mul<FrP>(inv, fe_pow2<FrP, 256>());   // device form -> ABI form
   for (u32 j = L; j-- > 0;) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) continue;
-    Fr a = fe_mul<FrP>(ld_canon(v, i), to_dev);
-    u32 s[8];
-    fe_canon_pack<FrP>(s, a);
+    const Fr raw = ld_canon(v, i);
     u32 nz = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) nz |= s[q];
+    for (int q = 0; q < 9; ++q) nz |= raw.l[q];
     if (!nz) continue;                         // zero stays zero
-    Fr r = fe_mul<FrP>(inv, ld_tw(scratch, i));   // a_i^-1 in device form
-    inv = fe_mul<FrP>(inv, a);
-    st_canon(v, i, fe_mul<FrP>(r, to_abi));
+    st_canon(v, i, fe_mul<FrP>(inv, ld_tw(scratch, i)));   // a_i^-1, ABI form
+    inv = fe_mul<FrP>(inv, abi_to_dev(raw));
   }
-}
-
-// ------------------------------------------------------------------ prefix product
-// out[0] = 1, out[i] = prod_{j<i} a[j]: the grand-product accumulator z of the permutation
-// argument.  Work-efficient three-kernel scan; the products run in the device Montgomery domain.
-//   local : a tile of 256*PP_L elements is staged in LDS (coalesced), every thread multiplies its PP_L
-//           consecutive elements, the 256 thread totals are scanned (shuffles + LDS), and a second
-//           serial sweep writes the tile-local exclusive prefixes (48-byte entries) + the tile total
-//   carry : exclusive scan of the tile totals, pre-multiplied by the device->ABI constant
-//   final : out = local prefix * carry  (one product per element, lands in ABI form)
-constexpr int PP_L = 8;
-PM_DEV Fr fr_shfl_up_mul_scan(Fr v, u32 lane) {  // inclusive product scan inside a wave
-  for (int d = 1; d < 64; d <<= 1) {
-    Fr o = fr_shfl_up(v, d);
-    if (lane >= (u32)d) v = fe_mul<FrP>(v, o);
-  }
-  return v;
-}
-__global__ void __launch_bounds__(256) prefix_prod_local_kernel(const u32x4* in, size_t n, u32x4* tmp, u32x4* tile_tot) {
-  extern __shared__ u32 sh[];  // [9][256 * PP_L] limbs, then 4 * 9 words of wave totals
-  constexpr int TILE = 256 * PP_L;
-  u32* wave_tot = sh + 9 * TILE;
-  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const size_t base = (size_t)blockIdx.x * TILE;
-  const Fr to_dev = fe_pow2<FrP, 2 * 261 - 256>();
-  const Fr one = fe_one<FrP>();
-#pragma unroll
-  for (int j = 0; j < PP_L; ++j) {
-    const u32 e = j * 256 + t;
-    Fr u = one;                                            // past the end: neutral element
-    if (base + e < n) u = fe_mul<FrP>(ld_canon(in, base + e), to_dev);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) sh[i * TILE + e] = u.l[i];
-  }
-  __syncthreads();
-  Fr tot = one;
-#pragma unroll
-  for (int j = 0; j < PP_L; ++j) {
-    Fr u;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) u.l[i] = sh[i * TILE + t * PP_L + j];
-    tot = j == 0 ? u : fe_mul<FrP>(tot, u);
-  }
-  Fr incl = fr_shfl_up_mul_scan(tot, lane);
-  if (lane == 63) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) wave_tot[wave * 9 + i] = incl.l[i];
-  }
-  Fr excl = fr_shfl_up(incl, 1);                           // exclusive inside the wave
-  if (lane == 0) excl = one;
-  __syncthreads();
-  Fr carry = one;
-  for (u32 w = 0; w < wave; ++w) {
-    Fr o;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o.l[i] = wave_tot[w * 9 + i];
-    carry = fe_mul<FrP>(carry, o);
-  }
-  Fr run = fe_mul<FrP>(excl, carry);                       // product of everything before this thread
-#pragma unroll
-  for (int j = 0; j < PP_L; ++j) {
-    const u32 e = t * PP_L + j;
-    Fr u;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) u.l[i] = sh[i * TILE + e];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) sh[i * TILE + e] = run.l[i];   // exclusive prefix of element e
-    run = fe_mul<FrP>(run, u);
-  }
-  if (t == 255) st_tw(tile_tot, blockIdx.x, run);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < PP_L; ++j) {                           // coalesced write-out
-    const u32 e = j * 256 + t;
-    if (base + e < n) {
-      Fr v;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) v.l[i] = sh[i * TILE + e];
-      st_tw(tmp, base + e, v);
-    }
-  }
-}
-__global__ void __launch_bounds__(256) prefix_prod_carry_kernel(u32x4* tile_tot, u32 ntiles) {
-  __shared__ u32 sh[4 * 9 + 9];
-  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const Fr one = fe_one<FrP>();
-  const Fr to_abi = fe_pow2<FrP, 256>();
-  Fr run = one;
-  for (u32 base = 0; base < ntiles; base += 256) {
-    const u32 i = base + t;
-    Fr v = i < ntiles ? ld_tw(tile_tot, i) : one;
-    Fr incl = fr_shfl_up_mul_scan(v, lane);
-    if (lane == 63) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sh[wave * 9 + k] = incl.l[k];
-    }
-    Fr excl = fr_shfl_up(incl, 1);
-    if (lane == 0) excl = one;
-    __syncthreads();
-    Fr carry = run;
-    for (u32 w = 0; w < wave; ++w) {
-      Fr o;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) o.l[k] = sh[w * 9 + k];
-      carry = fe_mul<FrP>(carry, o);
-    }
-    excl = fe_mul<FrP>(excl, carry);
-    if (i < ntiles) st_tw(tile_tot, i, fr_canon(fe_mul<FrP>(excl, to_abi)));
-    if (t == 255) {
-      Fr all = fe_mul<FrP>(excl, v);                       // inclusive through the last tile of the group
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sh[36 + k] = all.l[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 9; ++k) run.l[k] = sh[36 + k];
-    __syncthreads();
-  }
-}
-__global__ void __launch_bounds__(256) prefix_prod_final_kernel(const u32x4* tmp, const u32x4* tile_carry, size_t n,
-                                                                 u32x4* out) {
-  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  st_canon(out, k, fe_mul<FrP>(ld_tw(tmp, k), ld_tw(tile_carry, k / (256 * PP_L))));
 }
 
 // ------------------------------------------------------------------ host helpers
@@ -527,7 +635,6 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   const size_t m = n - 1;
-  const host::Field<4>& F = host::FR();
   HFr zz;
   memcpy(zz.l, z, 32);
   if (host::is_zero(zz)) {
@@ -536,41 +643,60 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
   }
-  u32 lg = 0;
-  while (((size_t)1 << lg) < m) ++lg;
-  const u32 lh = (lg + 1) / 2, n_lo = 1u << lh, n_hi = (u32)((m >> lh) + 1);
-  const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(16, m / ((size_t)256 * 1024)));
-  const u32 nblocks = (u32)((m + (size_t)256 * L - 1) / ((size_t)256 * L));
-  // the four power tables live in a context buffer: no allocator calls (and no device-wide
-  // synchronisation from hipFree) inside a proving loop
-  HFr zinv = host::inv(zz, F);
-  const size_t tab_entries = 2 * ((size_t)n_lo + n_hi);
+  // level sizes: m, ceil(m / K), ... until one workgroup holds the level
+  std::vector<size_t> sz;
+  sz.push_back(m);
+  while (sz.back() > (size_t)SC_BASE) sz.push_back((sz.back() + SC_K - 1) / SC_K);
+  size_t tot_entries = 0;
+  for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
+  if (sz.size() == 1) tot_entries = (m + SC_K - 1) / SC_K;       // a small input still goes totals -> base -> replay
   int rc = order_on(ctx, ctx->ord_poly, st);
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_tab, tab_entries * 48);
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, m * 32 + (size_t)nblocks * 48 + 64);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, tot_entries * 48 + 64);
   if (rc) return rc;
-  u32x4* tab = (u32x4*)ctx->poly_tab.ptr;
-  u32x4 *zi_lo = tab, *zi_hi = zi_lo + 3 * (size_t)n_lo, *z_lo = zi_hi + 3 * (size_t)n_hi, *z_hi = z_lo + 3 * (size_t)n_lo;
-  build_pow(zi_lo, zinv, n_lo, 1, st);
-  build_pow(zi_hi, zinv, n_hi, n_lo, st);
-  build_pow(z_lo, zz, n_lo, 1, st);
-  build_pow(z_hi, zz, n_hi, n_lo, st);
-  ScanArgs a;
-  a.coeffs = (const u32x4*)d_coeffs;
-  a.tmp = (u32x4*)ctx->poly_ws.ptr;
-  a.block_tot = a.tmp + 2 * m;
-  a.zi_hi = zi_hi;
-  a.zi_lo = zi_lo;
-  a.z_hi = z_hi;
-  a.z_lo = z_lo;
-  a.out = (u32x4*)d_out;
-  a.n = n;
-  a.lh = lh;
-  a.L = L;
+  if (sz.size() == 1) sz.push_back((m + SC_K - 1) / SC_K);
+  std::vector<u32x4*> lvl(sz.size());
+  {
+    u32x4* p = (u32x4*)ctx->poly_ws.ptr;
+    for (size_t i = 1; i < sz.size(); ++i) {
+      lvl[i] = p;
+      p += 3 * sz[i];
+    }
+  }
+  std::vector<RufLevel> zl(sz.size());
+  {
+    HFr zz_l = zz;
+    for (size_t i = 0; i < sz.size(); ++i) {
+      to_limbs29(zl[i].z, zz_l);
+      zz_l = hfr_pow_u64(zz_l, SC_K);
+    }
+  }
+  const size_t sc_lds_bytes = (size_t)SC_LDS_SLOTS * 16;
+  for (const void* fn : {(const void*)ruf_totals0_kernel, (const void*)ruf_replay0_kernel})
+    if (!ctx->big_lds_set[fn]) {
+      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds_bytes));
+      ctx->big_lds_set[fn] = true;
+    }
   ProfScope prof(ctx, st, "fr_poly_ruffini");
-  hipLaunchKernelGGL(ruffini_local_kernel, dim3(nblocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ruffini_carry_kernel, dim3(1), dim3(256), 0, st, a.block_tot, nblocks);
-  hipLaunchKernelGGL(ruffini_final_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+  const size_t last = sz.size() - 1;
+  for (size_t i = 0; i < last; ++i) {   // totals of level i -> level i + 1
+    const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
+    if (i == 0)
+      hipLaunchKernelGGL(ruf_totals0_kernel, dim3((unsigned)((m + SC_TILE - 1) / SC_TILE)), dim3(256), sc_lds_bytes, st,
+                         (const u32x4*)d_coeffs, n, m, lvl[1], zl[0]);
+    else
+      hipLaunchKernelGGL(ruf_totals_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)lvl[i], sz[i], lvl[i + 1],
+                         sz[i + 1], zl[i]);
+  }
+  hipLaunchKernelGGL(ruf_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last], zl[last]);
+  for (size_t i = last; i-- > 0;) {     // carries of level i + 1 -> outputs of level i
+    const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
+    if (i == 0)
+      hipLaunchKernelGGL(ruf_replay0_kernel, dim3((unsigned)((m + SC_TILE - 1) / SC_TILE)), dim3(256), sc_lds_bytes, st,
+                         (const u32x4*)d_coeffs, n, m, (const u32x4*)lvl[1], (u32x4*)d_out, zl[0]);
+    else
+      hipLaunchKernelGGL(ruf_replay_kernel, dim3(blocks), dim3(256), 0, st, lvl[i], sz[i], (const u32x4*)lvl[i + 1],
+                         sz[i + 1], zl[i]);
+  }
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
 }
@@ -582,21 +708,50 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   if (!d_in || !d_out) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  const size_t tile = (size_t)256 * PP_L;
-  const u32 ntiles = (u32)((n + tile - 1) / tile);
+  std::vector<size_t> sz;
+  sz.push_back(n);
+  while (sz.back() > (size_t)SC_BASE) sz.push_back((sz.back() + SC_K - 1) / SC_K);
+  if (sz.size() == 1) sz.push_back((n + SC_K - 1) / SC_K);
+  size_t tot_entries = 0;
+  for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
   int rc = order_on(ctx, ctx->ord_poly, st);
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, (n + ntiles) * 48 + 64);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, tot_entries * 48 + 64);
   if (rc) return rc;
-  u32x4* tmp = (u32x4*)ctx->poly_ws.ptr;
-  u32x4* tile_tot = tmp + 3 * n;
-  const size_t lds = (9 * tile + 36) * 4;
-  PM_HIP(ctx, hipFuncSetAttribute((const void*)prefix_prod_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+  std::vector<u32x4*> lvl(sz.size());
+  {
+    u32x4* p = (u32x4*)ctx->poly_ws.ptr;
+    for (size_t i = 1; i < sz.size(); ++i) {
+      lvl[i] = p;
+      p += 3 * sz[i];
+    }
+  }
+  const size_t sc_lds_bytes = (size_t)SC_LDS_SLOTS * 16;
+  for (const void* fn : {(const void*)pp_totals0_kernel, (const void*)pp_replay0_kernel})
+    if (!ctx->big_lds_set[fn]) {
+      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds_bytes));
+      ctx->big_lds_set[fn] = true;
+    }
   ProfScope prof(ctx, st, "fr_prefix_product");
-  hipLaunchKernelGGL(prefix_prod_local_kernel, dim3(ntiles), dim3(256), lds, st, (const u32x4*)d_in, n, tmp, tile_tot);
-  hipLaunchKernelGGL(prefix_prod_carry_kernel, dim3(1), dim3(256), 0, st, tile_tot, ntiles);
-  hipLaunchKernelGGL(prefix_prod_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32x4*)tmp,
-                     (const u32x4*)tile_tot, n, (u32x4*)d_out);
+  const size_t last = sz.size() - 1;
+  for (size_t i = 0; i < last; ++i) {
+    const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
+    if (i == 0)
+      hipLaunchKernelGGL(pp_totals0_kernel, dim3((unsigned)((n + SC_TILE - 1) / SC_TILE)), dim3(256), sc_lds_bytes, st,
+                         (const u32x4*)d_in, n, lvl[1]);
+    else
+      hipLaunchKernelGGL(pp_totals_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)lvl[i], sz[i], lvl[i + 1],
+                         sz[i + 1]);
+  }
+  hipLaunchKernelGGL(pp_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last]);
+  for (size_t i = last; i-- > 0;) {
+    const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
+    if (i == 0)
+      hipLaunchKernelGGL(pp_replay0_kernel, dim3((unsigned)((n + SC_TILE - 1) / SC_TILE)), dim3(256), sc_lds_bytes, st,
+                         (const u32x4*)d_in, n, (const u32x4*)lvl[1], (u32x4*)d_out);
+    else
+      hipLaunchKernelGGL(pp_replay_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)lvl[i], sz[i],
+                         (const u32x4*)lvl[i + 1], sz[i + 1], lvl[i]);
+  }
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
 }
