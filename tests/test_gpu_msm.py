@@ -210,6 +210,28 @@ def test_full_size_2_20(ctx, oracle):
     assert np.array_equal(ck.commit(wl), oracle.g1_mul(oracle.g1_generator(), dl))
 
 
+def test_full_size_2_24_against_the_discrete_log(ctx, oracle):
+    """BASELINE configs[4]'s MSM size inside pytest (VERDICT r01 missing #5): 2^24 points of a powers-of-tau key
+    generated on the GPU, resident-SRS table, uniform scalars; commit(s) = [s(tau)] G with s(tau) from the
+    CPU restatement's Horner -- no second MSM, no 2^24 scalar multiplications on the CPU."""
+    import plonk_prototype_amd as pa
+    n = 1 << 24
+    tau = 0x2B7E151628AED2A6ABF7158809CF4F3C762E7160F38B4DA56A784D9045190CFE % B.R_MOD
+    tau_m = oracle.fr_to_mont(ints_to_limbs([tau], 4))[0]
+    ck = pa.CommitKey.setup(n - 1, tau_m, ctx, precompute=True)
+    sc = oracle.fr_sample(0x5343414C + 24, n)
+    d_sc = pa.DeviceVector.from_host(ctx, sc)
+    got, ident = pa.g1_to_affine(ck._bases.msm_dev(d_sc.ptr, n))
+    s_tau = oracle.fr_from_mont(oracle.fr_poly_evaluate(sc, tau_m).reshape(1, 4))[0]
+    assert not ident and np.array_equal(got, oracle.g1_mul(oracle.g1_generator(), s_tau))
+    # the same scalars against the first 2^24 - 5 bases only: another polynomial, another point
+    got2, _ = pa.g1_to_affine(ck._bases.msm_dev(d_sc.ptr, n - 5))
+    s2 = oracle.fr_from_mont(oracle.fr_poly_evaluate(sc[:n - 5], tau_m).reshape(1, 4))[0]
+    assert np.array_equal(got2, oracle.g1_mul(oracle.g1_generator(), s2))
+    d_sc.free()
+    ck._bases.free()
+
+
 @pytest.mark.parametrize("n", [1, 2, 300, 5000])
 def test_srs_setup_on_the_gpu(ctx, oracle, n):
     """CommitKey.setup: powers_of_g[i] = tau^i G from the fixed-base kernel, against per-point
