@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -244,7 +245,7 @@ struct pm_prover_key {
   bool committed = false;
   u64 vk[NSEL + 4][12] = {};
   Transcript base{std::string("plonk")};
-  bool busy = false;                  // a proof is running on this key's workspace
+  std::atomic<bool> busy{false};       // a proof is running on this key's workspace
   hipStream_t side = nullptr;         // second stream: work that does not depend on the next challenge
   hipEvent_t ev_main = nullptr, ev_side = nullptr;
 };
@@ -492,11 +493,9 @@ namespace {
 struct BusyGuard {   // one proof at a time per key: the key owns the per-proof workspace
   pm_prover_key* pk;
   bool ok;
-  explicit BusyGuard(pm_prover_key* k) : pk(k), ok(!k->busy) {
-    if (ok) pk->busy = true;
-  }
+  explicit BusyGuard(pm_prover_key* k) : pk(k), ok(!k->busy.exchange(true)) {}
   ~BusyGuard() {
-    if (ok) pk->busy = false;
+    if (ok) pk->busy.store(false);
   }
 };
 }  // namespace
