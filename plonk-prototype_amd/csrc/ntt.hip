@@ -21,6 +21,7 @@ using host::HFr;
 // ------------------------------------------------------------------ kernel table
 typedef void (*pass_fn)(const NttPassArgs, const NttConsts);
 enum Role { ROLE_SINGLE = 0, ROLE_FIRST = 1, ROLE_MIDDLE = 2, ROLE_LAST = 3 };
+pass_fn find_pass4(int S, int LT, int role);   // radix-4 kernels (ntt4.hip)
 struct PassEntry {
   int S, LT, role;
   pass_fn fn;
@@ -47,7 +48,6 @@ static pass_fn find_pass(int S, int LT, int role) {
 }
 
 // radix-4 kernels (ntt4.hip)
-pass_fn find_pass4(int S, int LT, int role);
 size_t pass4_lds(int S, int LT);
 unsigned pass4_threads(int S, int LT);
 int build_step4_table(pm_ctx* ctx, void** out, const NttConsts& c, unsigned S, hipStream_t st);
@@ -57,10 +57,10 @@ struct Plan {
   int S[4] = {0, 0, 0, 0};
   int LT[4] = {0, 0, 0, 0};
 };
-static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10, int radix = 4) {
+static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10, int radix = 4, unsigned min_tiles = 256,
+                      unsigned batch = 1) {
   Plan p;
   if (log_n < 3) return p;  // tiny kernel
-  (void)radix;
   if (log_n <= 10) {  // one workgroup per transform; beyond 2^10 two passes over many CUs are faster
     p.npass = 1;     // (measured: a single 2^12 workgroup 52 us, two passes 35 us)
     p.S[0] = (int)log_n;
@@ -76,8 +76,16 @@ static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10, int radi
     // another), never fewer than 4 adjacent columns (64-byte runs per limb group)
     int lt = tile_log ? tile_log - p.S[i] : std::max(10 - p.S[i], 2);
     if (p.S[i] < 8 && lt > 11 - p.S[i]) lt = 11 - p.S[i];  // 2^12-element tiles exist for S >= 8 only
-    if (lt < 1) lt = 1;
-    if (tile_log == 10 && p.S[i] > 8) lt = 11 - p.S[i];     // 2^10-element tiles exist for S <= 8 only
+    if (!tile_log && radix == 4) {
+      // fill the chip: narrower tiles while there are fewer tiles than CUs (measured, profiles/r02_ntt_tile_ab.txt:
+      // 2^18: 61 -> 51 us, 2^19: 89 -> 72 us; no change from 2^20 up, where 4-column tiles already give 256)
+      while (lt > (p.S[i] >= 10 ? 0 : 1) && ((((size_t)batch << log_n) >> (p.S[i] + lt)) < min_tiles) &&
+             find_pass4(p.S[i], lt - 1, ROLE_LAST) != nullptr)
+        --lt;
+    }
+    if (lt < 0) lt = 0;
+    if (radix != 4 && lt < 1) lt = 1;                        // single-column tiles exist in the radix-4 family only
+    if (radix != 4 && tile_log == 10 && p.S[i] > 8) lt = 11 - p.S[i];
     lt = std::min(lt, (int)log_n - p.S[i]);
     p.LT[i] = lt;
   }
@@ -302,7 +310,8 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
   // or more passes with direct tables; otherwise multiplied explicitly (PASS_POST_SCALE)
   const bool direct_tw = log_n <= 26 && ctx->opt_ntt_direct_tw;  // tables of N x 36 B per twiddled pass and direction
 
-  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix);
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix,
+                        (unsigned)ctx->num_cus, batch);
   const bool scale_folded = dir && plan.npass > 1 && direct_tw;
   const u32 post = ((dir && !scale_folded) ? PASS_POST_SCALE : 0u) | ((dir && coset) ? PASS_POST_COSET : 0u);
   if (plan.npass == 0) {
@@ -421,7 +430,8 @@ extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
   // exactly the tables ntt_run() would build on the first transform of this size: domain and coset
   // tables, the step tables of the kernels the plan picks (radix-4 or radix-8 family), and the
   // inter-pass twiddle tables of both directions
-  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix);
+  Plan plan = make_plan(log_n, (int)ctx->opt_ntt_tile_log, (int)ctx->opt_ntt_max_radix, (int)ctx->opt_ntt_radix,
+                        (unsigned)ctx->num_cus, 1);
   const unsigned wide_glog = plan_wide_glog(plan);
   for (int dir = 0; dir < 2; ++dir) {
     NttDomainTables* dt;

@@ -16,7 +16,7 @@ struct Pass4Entry {
 };
 // single-pass shapes (LT = 0) and the multi-pass tiles of 2^11 elements (2^12 for S = 10)
 #define PM4_SINGLE(X) X(2, 0) X(3, 0) X(4, 0) X(5, 0) X(6, 0) X(7, 0) X(8, 0) X(9, 0) X(10, 0)
-#define PM4_MULTI(X) X(5, 6) X(6, 5) X(7, 4) X(8, 3) X(9, 2) X(10, 1) X(10, 2) X(5, 5) X(6, 4) X(7, 3) X(8, 2)
+#define PM4_MULTI(X) X(5, 6) X(6, 5) X(7, 4) X(8, 3) X(9, 2) X(10, 1) X(10, 2) X(5, 5) X(6, 4) X(7, 3) X(8, 2) X(10, 0) X(9, 1)
 static const Pass4Entry kPass4Table[] = {
 #define X(S, LT) {S, LT, 0, ntt_pass4_kernel<S, LT, false, false, false>},
     PM4_SINGLE(X)

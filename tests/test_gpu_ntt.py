@@ -22,7 +22,7 @@ def test_golden_vectors(ctx, oracle, golden):
             assert got == [int(h, 16) for h in v[name]], (v["log_n"], name)
 
 
-@pytest.mark.parametrize("k", list(range(0, 15)) + [16, 17, 18, 20])
+@pytest.mark.parametrize("k", list(range(0, 15)) + [16, 17, 18, 19, 20])
 def test_every_plan_against_oracle(ctx, oracle, k):
     n = 1 << k
     a = oracle.fr_sample(0x504C4F4E4B + k, n)
@@ -36,7 +36,8 @@ def test_every_plan_against_oracle(ctx, oracle, k):
 
 @pytest.mark.parametrize("radix", [4, 8])
 @pytest.mark.parametrize("k,tile,maxr", [(12, 12, 10), (16, 11, 10), (16, 12, 8), (20, 11, 10), (20, 12, 10),
-                                           (20, 11, 7), (18, 11, 6), (21, 12, 9), (20, 10, 8), (19, 10, 7)])
+                                           (20, 11, 7), (18, 11, 6), (21, 12, 9), (20, 10, 8), (19, 10, 7),
+                                           (20, 10, 10), (19, 10, 10), (18, 10, 10)])
 def test_plan_options(ctx, oracle, k, tile, maxr, radix):
     """Every kernel family / tile shape / pass split the tunables can select gives the same bits."""
     a = oracle.fr_sample(12 + k, 1 << k)
