@@ -23,13 +23,14 @@ from .host import Context, DeviceVector
 from .prover import Circuit
 
 
-def chain_circuit(n: int, seed: int = 1):
-    """-> (Circuit, witness [4, n, 4], public_inputs [n, 4]) for a power-of-two n >= 4."""
+def chain_circuit(n: int, seed: int = 1, public_rows=(0,)):
+    """-> (Circuit, witness [4, n, 4], public_inputs [n, 4]) for a power-of-two n >= 4; PI is non-zero on `public_rows`."""
     rng = random.Random(seed)
     rnd = lambda: rng.getrandbits(256) % R_MOD   # noqa: E731
     q = {k: [rnd() for _ in range(n)] for k in ("q_m", "q_l", "q_r", "q_4", "q_c")}
     pi = [0] * n
-    pi[0] = rnd()
+    for r_ in public_rows:
+        pi[r_] = rnd()
     v = [0] * (n + 1)
     v[0] = rnd()
     qm, ql, qr, q4, qc = q["q_m"], q["q_l"], q["q_r"], q["q_4"], q["q_c"]

@@ -279,6 +279,33 @@ def test_prove_is_deterministic_and_transcript_bound(ctx, oracle):
     assert ch["aw_shifted"] == p6.challenges["aw_shifted"]
 
 
+def test_several_public_inputs(ctx, oracle):
+    """Public inputs on several rows (first, inner, last): the dense PI vector the library builds from the
+    (position, value) pairs equals the one the oracle proves with, and each of them moves the challenges."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.field import fr_vec_from_limbs
+    n = 64
+    circuit, wit, pi = pa.synthetic.chain_circuit(n, 31, public_rows=(0, 5, 40, n - 1))
+    srs = _srs(oracle, n)
+    ck = pa.CommitKey(srs, ctx, precompute=True)
+    pk = PR.preprocess(circuit, ctx, ck)
+    proof = PR.prove(pk, ck, wit, pi)
+    pos, val = PR.sparse_public_inputs(pi)
+    assert pos.tolist() == [0, 5, 40, n - 1]
+    assert PR.prove(pk, ck, wit, (pos[::-1].copy(), val[::-1].copy())).to_bytes() != proof.to_bytes()   # order is bound too
+    sel = {k: fr_vec_from_limbs(getattr(circuit, k)) if getattr(circuit, k) is not None else [0] * n for k in PO.SELECTORS}
+    wi, pii = [fr_vec_from_limbs(wit[j]) for j in range(4)], fr_vec_from_limbs(pi)
+    exp = PO.prove(n, sel, circuit.sigma_index.tolist(), wi, pii, proof.challenges)
+    assert {k: _ints(oracle, v)[0] for k, v in proof.evaluations.items()} == exp["evals"]
+    pi_z = B.horner(B.ifft(pii, 6), proof.challenges["z"])
+    assert PR.check_identity(proof, n, pi_z)
+    for drop in range(4):
+        keep = [i for i in range(4) if i != drop]
+        other = PR.prove(pk, ck, wit, (pos[keep].copy(), val[keep].copy()))
+        assert other.challenges["beta"] != proof.challenges["beta"]
+
+
 def test_tampered_witness_fails_the_identity(ctx, oracle):
     import plonk_prototype_amd.prover as PR
     n = 64
