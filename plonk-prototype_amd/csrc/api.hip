@@ -214,6 +214,11 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_msm_chunk = value;
     return PM_OK;
   }
+  if (!strcmp(key, "msm_max_pairs")) {
+    if (value < 0 || value > 0x7fffffffL) return set_err(ctx, PM_ERR_BAD_ARG, "msm_max_pairs out of range");
+    ctx->opt_msm_max_pairs = value;
+    return PM_OK;
+  }
   if (!strcmp(key, "msm_lb")) {
     if (value < 0 || value > 1024 || (value & (value - 1))) return set_err(ctx, PM_ERR_BAD_ARG, "msm_lb must be a power of two");
     ctx->opt_msm_lb = value;

@@ -88,6 +88,7 @@ struct pm_ctx {
   long opt_ntt_max_radix = 10;   // log2 of the largest pass radix (multi-pass plans)
   long opt_ntt_direct_tw = 1;    // inter-pass twiddles from per-pass N x 36 B tables (1) or from the two-level tables + one product (0)
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
+  long opt_msm_max_pairs = 0;    // 0 = 2^31 - 1; a batched MSM with more (digit, point) pairs runs in halves
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
   int num_cus = 256;
 };

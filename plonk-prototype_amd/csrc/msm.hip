@@ -584,7 +584,16 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
   const size_t m = n * batch * g.nwin;  // (key, value) pairs
   const u32 nsets_all = g.nsets * batch;
-  if (m > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "batch * n * windows exceeds 2^31 pairs");
+  if (m > (ctx->opt_msm_max_pairs ? (size_t)ctx->opt_msm_max_pairs : (size_t)0x7fffffffu)) {
+    // pair indices are 31-bit: a batch too large for one pass (15 key polynomials of 2^24 coefficients) goes
+    // through in halves
+    if (batch == 1) return set_err(ctx, PM_ERR_LENGTH, "n * windows exceeds 2^31 pairs");
+    const u32 half = batch / 2;
+    int rc = msm_run(ctx, bases, offset, n, d_scalars, sc_stride, half, scalar_form, out_xyz, st);
+    if (rc) return rc;
+    return msm_run(ctx, bases, offset, n, (const char*)d_scalars + (size_t)half * sc_stride * 32, sc_stride, batch - half,
+                   scalar_form, out_xyz + 18 * half, st);
+  }
   // Entries per thread in the big kernel (measured, profiles/r01_msm_sweep.txt, r02_msm_sweep.txt): about
   // four times the mean run length m / #buckets when the grid allows it (then a run is split over at
   // most two neighbouring lanes and the in-wave join costs one addition), at least 128, and never so

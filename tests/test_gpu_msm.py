@@ -164,6 +164,15 @@ def test_batched_commits(ctx, oracle, table):
         assert np.array_equal(short[j], oracle.g1_msm(pts[:1000], polys[j, :1000], SCALAR_MONTGOMERY, 8))
     with pytest.raises(pa.Error):
         ck.commit_many(np.zeros((2, n + 1, 4), np.uint64))
+    # a batch over the 31-bit pair limit runs in halves (15 key polynomials of 2^24 coefficients do); forced
+    # here with a small limit, so that the five vectors go through in two or more passes
+    nwin = 256 // 13 + 1
+    ctx.set_option("msm_max_pairs", 2 * n * nwin)
+    try:
+        split = ck.commit_many(polys)
+    finally:
+        ctx.set_option("msm_max_pairs", 0)
+    assert np.array_equal(split, got)
 
 
 def test_sharded_msm_fold(ctx, oracle):
