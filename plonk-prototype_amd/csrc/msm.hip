@@ -622,9 +622,14 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   }
   const size_t l1_threads = (m + L1 - 1) / L1;
   const size_t total_buckets = (size_t)g.nbuckets * nsets_all;
-  // buckets per thread in the reduction: 8 once that still fills the chip (2^19 buckets), else 4 (measured)
-  const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : (total_buckets >= ((size_t)1 << 19) ? 8u : 4u),
-                              g.nbuckets);
+  // Buckets per thread in the reduction.  The reduction is VALU-bound, not a latency chain: a thread does 2 LB
+  // additions plus one small multiple (~35 operations) whatever LB is, one wave per SIMD already issues at
+  // ~87 % of what two reach, so the time is (waves per SIMD) x (2 LB + 35) x ~12 us and the best LB is the one that
+  // leaves about one wave per SIMD: all buckets of the launch / 2^16 -- 8 for one MSM at 2^19 buckets, 32 for a batch
+  // of four (measured, profiles/r02_msm_lb.txt) -- and 4 below 2^18 buckets, where the later sum stages dominate.
+  u32 lb_auto = 4;
+  while (lb_auto < 64 && (total_buckets / (2 * lb_auto)) >= ((size_t)ctx->num_cus * 4 * 64)) lb_auto *= 2;
+  const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : lb_auto, g.nbuckets);
   const u32 chunks_per_win = g.nbuckets / LB;
   const size_t total_chunks = (size_t)chunks_per_win * nsets_all;
 
