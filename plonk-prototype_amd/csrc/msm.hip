@@ -439,68 +439,107 @@ __global__ void __launch_bounds__(128) msm_accumulate_ln_kernel(const AccArgs a)
 }
 
 // ------------------------------------------------------------------ 4: bucket reduce
-// red[w * nt + t] = sum_{b in chunk t} (b + 1) * B[w][b]
-// One kernel (running sum and sum of running sums side by side: 371 VGPRs, one wave per SIMD) when the chunks
-// fill the chip once -- a single MSM: the chain of dependent additions is what counts -- and a two-kernel form
-// whose kernels each hold ONE accumulator beside the loaded point (two waves per SIMD) when there are more
-// chunks than that (a batch of MSMs: throughput counts; measured in a 2^20-gate proof: 6.9 instead of 7.7 ms):
-//   suffix  B[b0 + i] <- S_i = B[b0 + i] + ... + B[b0 + lb - 1]          (in place, lb - 1 additions per thread)
-//   weight  sum_i S_i + b0 * S_0                                        (lb - 1 additions + one small multiple)
-__global__ void __launch_bounds__(64) msm_bucket_chunk_kernel(const u32x4* buckets, u32 nbuckets, u32 lb,
-                                                              u32 total_chunks, u32x4* red) {
-  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= total_chunks) return;
-  const u32 nt = nbuckets / lb;
-  const u32 w = gid / nt, t = gid % nt;
-  const u32 b0 = t * lb;
-  const u32x4* B = buckets + (size_t)16 * ((size_t)w * nbuckets);
+// sum_b (b + 1) B_b for every bucket set, as a hierarchy of wave-level reductions with NO per-thread scalar
+// multiple (r01 / early r02: each thread finished its chunk with (chunk offset) x (chunk sum), ~35 dependent
+// group operations -- two thirds of the kernel).
+//   level 1 (msm_bucket_wave_kernel): a thread takes `lb` consecutive buckets with the two running sums
+//       S = sum B,  T = sum (i + 1) B_i,  so its chunk t = 64 w + lane contributes T + lb t S.
+//       Across the lanes of the wave: the suffix scan P_l = sum_{l' >= l} S_l' (6 additions) gives
+//       sum_l l S_l = sum_{l >= 1} P_l and W_w = P_0, so the wave writes
+//           a_w = sum_l (T_l + lb [l >= 1] P_l)       (log2 lb doublings, one addition, a 6-step tree)
+//           W_w = sum_l S_l
+//       and the set's total is  sum_w (a_w + 64 lb w W_w).
+//   level k >= 2 (msm_level_kernel): 64 consecutive items per wave.  Sequences that only need adding up
+//       (a, and the index-weighted sums v of the earlier levels) get a 6-step tree each; the sequence W is
+//       scanned and summed as above and yields v' = sum_l l W_l and W' = sum_l W_l for the next level.
+//       Independent waves (blockIdx.y) take the independent jobs.
+//   The last level leaves  F_0 = sum a,  F_1 .. F_L  (v of level 2 .. L + 1) per set; the powers of two that
+//   belong to them (64 lb, 64^2 lb, ..) are applied in the host fold, where a doubling costs well under 1 us.
+// 2^19 buckets, lb = 8: 16 + 16 dependent operations in level 1, 12 and 10 in the two small levels that follow
+// (before: 16 + 35 + 1, then two sum stages of 10).
+__global__ void __launch_bounds__(64) msm_bucket_wave_kernel(const u32x4* buckets, u32 nbuckets, u32 lb, u32 log_lb,
+                                                             u32 n1, u32 finalize, u32x4* out_a, u32x4* out_w) {
+  const u32 set = blockIdx.x / n1, w = blockIdx.x % n1, lane = threadIdx.x;
+  const u32 nt = nbuckets / lb;  // chunks per set
+  const u32 t = 64 * w + lane;
   Xyzz running = xyzz_identity(), sum = xyzz_identity();
-  for (u32 i = lb; i-- > 0;) {
-    Xyzz b = ld_xyzz(B, b0 + i);
-    running = xyzz_add(running, b);
-    sum = xyzz_add(sum, running);
+  if (t < nt) {
+    const u32x4* B = buckets + (size_t)16 * ((size_t)set * nbuckets + (size_t)t * lb);
+    for (u32 i = lb; i-- > 0;) {
+      Xyzz b = ld_xyzz(B, i);
+      running = xyzz_add(running, b);
+      sum = xyzz_add(sum, running);
+    }
   }
-  sum = xyzz_add(sum, xyzz_mul_small(running, b0));
-  st_xyzz(red, gid, sum);
-}
-__global__ void __launch_bounds__(64, 2) msm_bucket_suffix_kernel(u32x4* buckets, u32 nbuckets, u32 lb, u32 total_chunks) {
-  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= total_chunks) return;
-  const u32 nt = nbuckets / lb;
-  const u32 w = gid / nt, t = gid % nt;
-  u32x4* B = buckets + (size_t)16 * ((size_t)w * nbuckets + (size_t)t * lb);
-  Xyzz running = ld_xyzz(B, lb - 1);
-  for (u32 i = lb - 1; i-- > 0;) {
-    running = xyzz_add(running, ld_xyzz(B, i));
-    st_xyzz(B, i, running);
+  for (int d = 1; d < 64; d <<= 1) {
+    Xyzz o = xyzz_shfl_down(running, d);
+    if (lane + d < 64) running = xyzz_add(running, o);
   }
-}
-__global__ void __launch_bounds__(64, 2) msm_bucket_weight_kernel(const u32x4* buckets, u32 nbuckets, u32 lb,
-                                                                   u32 total_chunks, u32x4* red) {
-  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= total_chunks) return;
-  const u32 nt = nbuckets / lb;
-  const u32 w = gid / nt, t = gid % nt;
-  const u32 b0 = t * lb;
-  const u32x4* B = buckets + (size_t)16 * ((size_t)w * nbuckets + b0);
-  Xyzz sum = xyzz_mul_small(ld_xyzz(B, 0), b0 + 1);      // (b0 + 1) S_0: S_0 itself plus the chunk's offset
-  for (u32 i = 1; i < lb; ++i) sum = xyzz_add(sum, ld_xyzz(B, i));
-  st_xyzz(red, gid, sum);
-}
-// Sum of `per` consecutive entries per wave: out[g] = sum in[g*per .. (g+1)*per).  One wave per
-// workgroup (the group law wants the whole register file): each lane adds per/64 entries, then a
-// shuffle tree.  `finalize` reduces the coordinates below 2p for the host.
-__global__ void __launch_bounds__(64) msm_sum_kernel(const u32x4* in, u32 per, u32x4* out, u32 finalize) {
-  const u32 g = blockIdx.x, lane = threadIdx.x;
-  Xyzz acc = xyzz_identity();
-  for (u32 i = lane; i < per; i += 64) acc = xyzz_add(acc, ld_xyzz(in, (size_t)g * per + i));
-  for (int d = 32; d > 0; d >>= 1) acc = xyzz_add(acc, xyzz_shfl_down(acc, d));
+  if (lane == 0) st_xyzz(out_w, blockIdx.x, running);
+  if (lane == 0) running = xyzz_identity();
+  for (u32 k = 0; k < log_lb; ++k) running = xyzz_double(running);
+  sum = xyzz_add(sum, running);
+  for (int d = 32; d > 0; d >>= 1) {   // lanes >= d would add their own value to itself (the slow P + P path)
+    Xyzz o = xyzz_shfl_down(sum, d);
+    if (lane < (u32)d) sum = xyzz_add(sum, o);
+  }
   if (lane == 0) {
-    if (finalize && !acc.inf) {  // the host needs values that fit 384 bits
+    if (finalize && !sum.inf) {  // the host needs values that fit 384 bits
+      sum.x = fe_mul<FpP>(sum.x, fe_one<FpP>());
+      sum.y = fe_mul<FpP>(sum.y, fe_one<FpP>());
+    }
+    st_xyzz(out_a, blockIdx.x, sum);
+  }
+}
+
+struct LevelArgs {
+  const u32x4* plain_in0;   // sequences to add up: per set n_items entries
+  const u32x4* plain_in1;
+  const u32x4* plain_in2;
+  u32x4* plain_out0;        // per set n_groups entries
+  u32x4* plain_out1;
+  u32x4* plain_out2;
+  const u32x4* w_in;        // the sequence W: scanned
+  u32x4* v_out;             // sum_l l W_l per group
+  u32x4* w_out;             // sum_l W_l per group
+  u32 n_plain;
+  u32 n_items;
+  u32 n_groups;             // ceil(n_items / 64)
+  u32 finalize;
+};
+__global__ void __launch_bounds__(64) msm_level_kernel(const LevelArgs a) {
+  const u32 set = blockIdx.x / a.n_groups, g = blockIdx.x % a.n_groups, job = blockIdx.y, lane = threadIdx.x;
+  const u32 idx = 64 * g + lane;
+  const bool live = idx < a.n_items;
+  const size_t src = (size_t)set * a.n_items + idx;
+  Xyzz acc = xyzz_identity();
+  u32x4* out;
+  if (job < a.n_plain) {
+    const u32x4* in = job == 0 ? a.plain_in0 : (job == 1 ? a.plain_in1 : a.plain_in2);
+    out = job == 0 ? a.plain_out0 : (job == 1 ? a.plain_out1 : a.plain_out2);
+    if (live) acc = ld_xyzz(in, src);
+  } else {
+    out = a.v_out;
+    if (live) acc = ld_xyzz(a.w_in, src);
+    for (int d = 1; d < 64; d <<= 1) {
+      Xyzz o = xyzz_shfl_down(acc, d);
+      if (lane + d < 64) acc = xyzz_add(acc, o);
+    }
+    if (lane == 0) {
+      st_xyzz(a.w_out, blockIdx.x, acc);
+      acc = xyzz_identity();
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    Xyzz o = xyzz_shfl_down(acc, d);
+    if (lane < (u32)d) acc = xyzz_add(acc, o);
+  }
+  if (lane == 0) {
+    if (a.finalize && !acc.inf) {
       acc.x = fe_mul<FpP>(acc.x, fe_one<FpP>());
       acc.y = fe_mul<FpP>(acc.y, fe_one<FpP>());
     }
-    st_xyzz(out, g, acc);
+    st_xyzz(out, blockIdx.x, acc);
   }
 }
 
@@ -622,16 +661,27 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   }
   const size_t l1_threads = (m + L1 - 1) / L1;
   const size_t total_buckets = (size_t)g.nbuckets * nsets_all;
-  // Buckets per thread in the reduction.  The reduction is VALU-bound, not a latency chain: a thread does 2 LB
-  // additions plus one small multiple (~35 operations) whatever LB is, one wave per SIMD already issues at
-  // ~87 % of what two reach, so the time is (waves per SIMD) x (2 LB + 35) x ~12 us and the best LB is the one that
-  // leaves about one wave per SIMD: all buckets of the launch / 2^16 -- 8 for one MSM at 2^19 buckets, 32 for a batch
-  // of four (measured, profiles/r02_msm_lb.txt) -- and 4 below 2^18 buckets, where the later sum stages dominate.
-  u32 lb_auto = 4;
-  while (lb_auto < 64 && (total_buckets / (2 * lb_auto)) >= ((size_t)ctx->num_cus * 4 * 64)) lb_auto *= 2;
+  // Buckets per thread in level 1 of the reduction (a power of two).  Level 1 keeps two accumulators and the
+  // loaded point in registers (256 VGPRs + 17 AGPRs: one wave per SIMD; forcing two spills and is slower:
+  // 938 vs 650 us), a lone wave issues one VALU instruction per ~7 cycles, and a thread does 2 LB + 16 + log2 LB
+  // group operations, so the time is (waves per SIMD, rounded up) x that count x ~13 us: the best LB leaves one
+  // wave per SIMD -- all buckets of the launch / 2^16: 8 for one MSM at 2^19 buckets, 32 for a batch of four, 1 for
+  // an 8-way shard with 2^15 buckets (profiles/r02_msm_lb.txt).
+  u32 lb_auto = 1;
+  while (lb_auto < 64 && (total_buckets / lb_auto) > ((size_t)ctx->num_cus * 4 * 64)) lb_auto *= 2;
   const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : lb_auto, g.nbuckets);
+  u32 log_lb = 0;
+  while ((1u << log_lb) < LB) ++log_lb;
   const u32 chunks_per_win = g.nbuckets / LB;
-  const size_t total_chunks = (size_t)chunks_per_win * nsets_all;
+  // waves per set in level 1, then the group counts of the follow-up levels (64 items per wave) down to one
+  const u32 n1 = (chunks_per_win + 63) / 64;
+  std::vector<u32> lvl_groups;
+  for (u32 items = n1; items > 1;) {
+    items = (items + 63) / 64;
+    lvl_groups.push_back(items);
+  }
+  const u32 n_levels = (u32)lvl_groups.size();   // follow-up launches; the host receives n_levels + 1 points per set
+  if (n_levels > 3) return set_err(ctx, PM_ERR_BAD_ARG, "internal: bucket reduction deeper than four levels");
 
   // workspace layout
   size_t sort_tmp = 0;
@@ -652,9 +702,12 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     o_ppts[i] = take(lv[i].len * 256);
   }
   const size_t o_heads = take(lv.size() > 1 ? l1_threads * 256 : 0);
-  const size_t o_red = take(total_chunks * 256);
-  const size_t o_red2 = take((total_chunks / 256 + nsets_all) * 256);
-  const size_t o_win = take((size_t)nsets_all * 256);
+  // level 1 writes (a, W) per wave; level k writes its plain sums, v and W per group; the last level's plain sums
+  // and v go to the slots of o_win (slot j: one point per set, nsets_all points per slot) that the host reads
+  const size_t o_l1a = take((size_t)nsets_all * n1 * 256), o_l1w = take((size_t)nsets_all * n1 * 256);
+  std::vector<size_t> o_lvl(n_levels);
+  for (u32 k = 0; k < n_levels; ++k) o_lvl[k] = take((size_t)(k + 3) * nsets_all * lvl_groups[k] * 256);
+  const size_t o_win = take((size_t)(n_levels + 1) * nsets_all * 256);
   int rc = ensure_buffer(ctx, ctx->msm_ws, off);
   if (rc) return rc;
   char* ws = (char*)ctx->msm_ws.ptr;
@@ -662,10 +715,10 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   u32 *keys1 = (u32*)(ws + o_keys1), *vals1 = (u32*)(ws + o_vals1);
   u32x4* buckets = (u32x4*)(ws + o_buckets);
 
-  if (ctx->msm_host_pinned_bytes < (size_t)nsets_all * 256) {
+  if (ctx->msm_host_pinned_bytes < (size_t)(n_levels + 1) * nsets_all * 256) {
     if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
     ctx->msm_host_pinned = nullptr;
-    ctx->msm_host_pinned_bytes = std::max<size_t>(64, nsets_all) * 256;
+    ctx->msm_host_pinned_bytes = std::max<size_t>(64, (size_t)(n_levels + 1) * nsets_all) * 256;
     PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, ctx->msm_host_pinned_bytes, hipHostMallocDefault));
   }
 
@@ -719,46 +772,67 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
     PM_HIP(ctx, hipGetLastError());
   }
-  // 4 bucket reduce
+  // 4 bucket reduce: level 1 over the buckets, then the small levels (see msm_bucket_wave_kernel)
+  u32x4* win = (u32x4*)(ws + o_win);
+  const size_t slot = (size_t)nsets_all * 16;   // u32x4 per slot of o_win
   {
-  ProfScope prof(ctx, st, "msm_bucket_chunk");
-  if (total_chunks > (size_t)ctx->num_cus * 4 * 64) {   // more than one wave per SIMD: throughput-bound
-    hipLaunchKernelGGL(msm_bucket_suffix_kernel, dim3((unsigned)((total_chunks + 63) / 64)), dim3(64), 0, st, buckets,
-                       g.nbuckets, LB, (u32)total_chunks);
-    hipLaunchKernelGGL(msm_bucket_weight_kernel, dim3((unsigned)((total_chunks + 63) / 64)), dim3(64), 0, st,
-                       (const u32x4*)buckets, g.nbuckets, LB, (u32)total_chunks, (u32x4*)(ws + o_red));
-  } else {
-    hipLaunchKernelGGL(msm_bucket_chunk_kernel, dim3((unsigned)((total_chunks + 63) / 64)), dim3(64), 0, st,
-                       (const u32x4*)buckets, g.nbuckets, LB, (u32)total_chunks, (u32x4*)(ws + o_red));
-  }
+    ProfScope prof(ctx, st, "msm_bucket_chunk");
+    hipLaunchKernelGGL(msm_bucket_wave_kernel, dim3(nsets_all * n1), dim3(64), 0, st, (const u32x4*)buckets, g.nbuckets, LB,
+                       log_lb, n1, n_levels == 0 ? 1u : 0u, n_levels == 0 ? win : (u32x4*)(ws + o_l1a),
+                       (u32x4*)(ws + o_l1w));
   }
   PM_HIP(ctx, hipGetLastError());
-  {
-    // two stages: 256 entries per wave, then what is left per window
+  if (n_levels) {
     ProfScope prof(ctx, st, "msm_window_sum");
-    const u32 per1 = std::min<u32>(256, chunks_per_win);
-    const u32 groups = chunks_per_win / per1;  // per window
-    if (groups > 1) {
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(nsets_all * groups), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
-                         (u32x4*)(ws + o_red2), 0u);
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(nsets_all), dim3(64), 0, st, (const u32x4*)(ws + o_red2), groups,
-                         (u32x4*)(ws + o_win), 1u);
-    } else {
-      hipLaunchKernelGGL(msm_sum_kernel, dim3(nsets_all), dim3(64), 0, st, (const u32x4*)(ws + o_red), per1,
-                         (u32x4*)(ws + o_win), 1u);
+    const u32x4* plain[3] = {(const u32x4*)(ws + o_l1a), nullptr, nullptr};
+    const u32x4* w_in = (const u32x4*)(ws + o_l1w);
+    u32 items = n1;
+    for (u32 k = 0; k < n_levels; ++k) {
+      const u32 groups = lvl_groups[k], n_plain = k + 1;
+      const bool last = k + 1 == n_levels;
+      const size_t per = (size_t)nsets_all * groups * 16;   // u32x4 per output array of this level
+      u32x4* base = (u32x4*)(ws + o_lvl[k]);
+      LevelArgs la;
+      memset(&la, 0, sizeof la);
+      la.plain_in0 = plain[0]; la.plain_in1 = plain[1]; la.plain_in2 = plain[2];
+      u32x4* pout[3] = {nullptr, nullptr, nullptr};
+      for (u32 j = 0; j < n_plain; ++j) pout[j] = last ? win + j * slot : base + j * per;
+      la.plain_out0 = pout[0]; la.plain_out1 = pout[1]; la.plain_out2 = pout[2];
+      la.w_in = w_in;
+      la.v_out = last ? win + n_plain * slot : base + n_plain * per;
+      la.w_out = base + (n_plain + 1) * per;
+      la.n_plain = n_plain;
+      la.n_items = items;
+      la.n_groups = groups;
+      la.finalize = last ? 1u : 0u;
+      hipLaunchKernelGGL(msm_level_kernel, dim3(nsets_all * groups, n_plain + 1), dim3(64), 0, st, la);
+      for (u32 j = 0; j < n_plain; ++j) plain[j] = pout[j];
+      if (!last) plain[n_plain] = la.v_out;
+      w_in = la.w_out;
+      items = groups;
     }
   }
   PM_HIP(ctx, hipGetLastError());
-  // 5 host fold
-  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)nsets_all * 256, hipMemcpyDeviceToHost, st));
+  // 5 host fold: per set F_0 + 64 LB (F_1 + 64 (F_2 + 64 F_3)), then the windows
+  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)(n_levels + 1) * nsets_all * 256,
+                             hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
   const u32* hw = (const u32*)ctx->msm_host_pinned;
+  auto set_total = [&](size_t set) {
+    XYZZ acc = xyzz_to_host(hw + 64 * ((size_t)n_levels * nsets_all + set));
+    for (u32 k = n_levels; k-- > 0;) {
+      const u32 dbl = k == 0 ? 6 + log_lb : 6;
+      for (u32 d = 0; d < dbl; ++d) acc = host::xyzz_double(acc);
+      acc = host::xyzz_add(acc, xyzz_to_host(hw + 64 * ((size_t)k * nsets_all + set)));
+    }
+    return acc;
+  };
   for (u32 j = 0; j < batch; ++j) {
     XYZZ total = host::xyzz_identity();
-    for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no doublings at all
+    for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no window doublings at all
       if (w + 1 < g.nsets)
         for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
-      total = host::xyzz_add(total, xyzz_to_host(hw + 64 * ((size_t)j * g.nsets + w)));
+      total = host::xyzz_add(total, set_total((size_t)j * g.nsets + w));
     }
     write_projective(out_xyz + 18 * j, total);
   }
