@@ -161,6 +161,99 @@ PM_DEV Xyzz xyzz_mul_small(const Xyzz& p, u32 k) {
   return r;
 }
 
+// ---- one point on TWO neighbouring lanes --------------------------------------------------------
+// The reduction kernels after the big accumulate run few waves with long chains of dependent group
+// operations, and a lone wave issues one VALU instruction per ~7 cycles.  There a point lives on a lane pair:
+// the even lane ("A") holds c0 = X, c1 = ZZ, the odd lane ("B") holds c0 = Y, c1 = ZZZ.  Both lanes run the
+// SAME instruction stream; an addition is 7 rounds of one field product per lane instead of 14 on one lane
+// (doubling: 5 instead of 9), with four (two) exchanges of one field element between the lanes of the pair
+// (DPP quad_perm, no LDS).  Same formulas, same bound classes and the same after-the-fact handling of
+// P + P / P - P as xyzz_add / xyzz_double above; the `inf` flag is kept equal on both lanes.
+struct Half {
+  Fp c0, c1;
+  bool inf;
+};
+PM_DEV Fp fp_pair_swap(const Fp& v) {   // lanes 2k <-> 2k + 1
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xB1, 0xF, 0xF, false);
+  return r;
+}
+PM_DEV Fp fp_select(bool c, const Fp& a, const Fp& b) {   // c ? a : b
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+PM_DEV Half half_identity() {
+  Half r;
+  r.c0 = fe_zero<FpP>();
+  r.c1 = fe_zero<FpP>();
+  r.inf = true;
+  return r;
+}
+// 2 p (dbl-2008-s-1)
+PM_DEV Half half_double(const Half& p, bool isB) {
+  if (p.inf) return p;
+  const Fp t = isB ? fe_add<FpP>(p.c0, p.c0) : p.c0;       // B: U = 2 y (2+, <10);  A: x
+  const Fp s1 = fe_sqr<FpP>(t);                             // A: XX;  B: V
+  const Fp s1o = fp_pair_swap(s1);                          // A: V;   B: XX
+  const Fp s2 = fe_mul<FpP>(t, fp_select(isB, s1, s1o));    // A: S = x V;  B: W = U V
+  const Fp xx = fp_select(isB, s1o, s1);
+  const Fp M = fe_add<FpP>(fe_add<FpP>(xx, xx), xx);        // (3, <6) on both lanes
+  const Fp s3 = fe_mul<FpP>(fp_select(isB, s2, M), fp_select(isB, p.c0, M));   // A: MM;  B: YB = W y
+  Half r;
+  r.c1 = fe_mul<FpP>(fp_select(isB, s2, s1o), p.c1);        // A: ZZ3 = V zz;  B: ZZZ3 = W zzz
+  const Fp x3 = fe_norm<FpP>(fe_sub<FpP, 5, 1>(s3, fe_add<FpP>(s2, s2)));      // A: X3 (1+, <7); B: unused
+  const Fp D = fe_sub<FpP, 8, 1>(s2, x3);                   // (4, <10)
+  const Fp ya = fe_mul<FpP>(M, D);                          // A: YA
+  const Fp yao = fp_pair_swap(ya);                          // B: YA
+  r.c0 = fp_select(isB, fe_norm<FpP>(fe_sub<FpP, 3, 1>(yao, s3)), x3);
+  r.inf = false;
+  return r;
+}
+// a + b (add-2008-s)
+PM_DEV Half half_add(const Half& a, const Half& b, bool isB) {
+  if (a.inf) return b;
+  if (b.inf) return a;
+  const Fp m1 = fe_mul<FpP>(a.c0, b.c1);                    // A: U1 = X1 ZZ2;   B: S1 = Y1 ZZZ2
+  const Fp m2 = fe_mul<FpP>(b.c0, a.c1);                    // A: U2;            B: S2
+  const Fp d = fe_norm<FpP>(fe_sub<FpP, 3, 1>(m2, m1));     // A: P;  B: R   (1+, <5)
+  const Fp e = fe_sqr<FpP>(d);                              // A: PP; B: RR
+  const Fp dO = fp_pair_swap(d);                            // A: R;  B: P
+  const Fp eO = fp_pair_swap(e);                            // A: RR; B: PP
+  const Fp z12 = fe_mul<FpP>(a.c1, b.c1);                   // A: ZZ1 ZZ2;  B: ZZZ1 ZZZ2
+  const Fp f = fe_mul<FpP>(fp_select(isB, dO, m1), fp_select(isB, eO, e));   // A: Q = U1 PP;  B: PPP = P PP
+  const Fp fO = fp_pair_swap(f);                            // A: PPP;  B: Q
+  Half r;
+  r.c1 = fe_mul<FpP>(z12, fp_select(isB, f, e));            // A: ZZ3 = ZZ1 ZZ2 PP;  B: ZZZ3 = ZZZ1 ZZZ2 PPP
+  const Fp rr = fp_select(isB, e, eO), ppp = fp_select(isB, f, fO), q = fp_select(isB, fO, f);
+  const Fp t = fe_sub<FpP, 3, 1>(rr, ppp);                  // (4, <5)
+  const Fp x3 = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(q, q)));   // (1+, <10), both lanes
+  const Fp D = fe_sub<FpP, 11, 1>(q, x3);                   // (4, <13)
+  const Fp h = fe_mul<FpP>(fp_select(isB, m1, dO), fp_select(isB, f, D));   // A: YA = R D;  B: YB = S1 PPP
+  const Fp hO = fp_pair_swap(h);                            // B: YA
+  r.c0 = fp_select(isB, fe_norm<FpP>(fe_sub<FpP, 3, 1>(hO, h)), x3);
+  r.inf = false;
+  if (fp_is_zero_product(r.c1)) {     // P = 0 mod p makes ZZ3 and ZZZ3 vanish together: both lanes agree
+    if (fp_is_zero_lazy(fp_select(isB, d, dO)))   // R
+      r = half_double(a, isB);
+    else
+      r = half_identity();
+  }
+  return r;
+}
+PM_DEV Half half_shfl_down(const Half& v, int pairs) {
+  Half r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    r.c0.l[i] = __shfl_down(v.c0.l[i], 2 * pairs);
+    r.c1.l[i] = __shfl_down(v.c1.l[i], 2 * pairs);
+  }
+  r.inf = __shfl_down((int)v.inf, 2 * pairs) != 0;
+  return r;
+}
+
 // ---- memory format: 4 coordinates x 16 words (14 limbs + 2 pad) = 256 bytes ---------------
 PM_DEV Fp ld_fp_limbs(const u32x4* p) {
   u32x4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -202,6 +295,34 @@ PM_DEV void st_xyzz(u32x4* base, size_t idx, const Xyzz& v) {
   st_fp_limbs(p + 4, v.y);
   st_fp_limbs(p + 8, v.zz);
   st_fp_limbs(p + 12, v.zzz);
+}
+
+// one lane's half of a point in the 256-byte record: A reads / writes X and ZZ, B reads / writes Y and ZZZ
+PM_DEV Half ld_half(const u32x4* base, size_t idx, bool isB) {
+  const u32x4* p = base + 16 * idx;
+  const Fp zz = ld_fp_limbs(p + 8);
+  u32 z = 0;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) z |= zz.l[i];
+  Half r;
+  r.inf = (z == 0);
+  r.c0 = ld_fp_limbs(p + (isB ? 4 : 0));
+  r.c1 = isB ? ld_fp_limbs(p + 12) : zz;
+  return r;
+}
+PM_DEV void st_half(u32x4* base, size_t idx, const Half& v, bool isB) {
+  u32x4* p = base + 16 * idx;
+  if (v.inf) {
+    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      p[(isB ? 4 : 0) + i] = z;
+      p[(isB ? 12 : 8) + i] = z;
+    }
+    return;
+  }
+  st_fp_limbs(p + (isB ? 4 : 0), v.c0);
+  st_fp_limbs(p + (isB ? 12 : 8), v.c1);
 }
 
 }  // namespace pm

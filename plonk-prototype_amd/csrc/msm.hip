@@ -439,56 +439,58 @@ __global__ void __launch_bounds__(128) msm_accumulate_ln_kernel(const AccArgs a)
 }
 
 // ------------------------------------------------------------------ 4: bucket reduce
+static constexpr u32 GROUP = 32;   // items per wave in the reduction: one per lane PAIR (ec.cuh, struct Half)
 // sum_b (b + 1) B_b for every bucket set, as a hierarchy of wave-level reductions with NO per-thread scalar
-// multiple (r01 / early r02: each thread finished its chunk with (chunk offset) x (chunk sum), ~35 dependent
-// group operations -- two thirds of the kernel).
-//   level 1 (msm_bucket_wave_kernel): a thread takes `lb` consecutive buckets with the two running sums
-//       S = sum B,  T = sum (i + 1) B_i,  so its chunk t = 64 w + lane contributes T + lb t S.
-//       Across the lanes of the wave: the suffix scan P_l = sum_{l' >= l} S_l' (6 additions) gives
+// multiple (r01 / early r02: each thread finished its chunk with (chunk offset) x (chunk sum)), and with every
+// point held by a PAIR of lanes (struct Half in ec.cuh: 7 field-product rounds per addition instead of 14).
+// These kernels run one or two waves per SIMD with long dependent chains, and a lone wave issues one VALU
+// instruction per ~7 cycles: halving the instructions per group operation is what shortens them.
+//   level 1 (msm_bucket_wave_kernel): a lane pair takes `lb` consecutive buckets with the two running sums
+//       S = sum B,  T = sum (i + 1) B_i,  so its chunk t = 32 w + l contributes T + lb t S.
+//       Across the 32 pairs of the wave: the suffix scan P_l = sum_{l' >= l} S_l' (5 additions) gives
 //       sum_l l S_l = sum_{l >= 1} P_l and W_w = P_0, so the wave writes
-//           a_w = sum_l (T_l + lb [l >= 1] P_l)       (log2 lb doublings, one addition, a 6-step tree)
+//           a_w = sum_l (T_l + lb [l >= 1] P_l)       (log2 lb doublings, one addition, a 5-step tree)
 //           W_w = sum_l S_l
-//       and the set's total is  sum_w (a_w + 64 lb w W_w).
-//   level k >= 2 (msm_level_kernel): 64 consecutive items per wave.  Sequences that only need adding up
-//       (a, and the index-weighted sums v of the earlier levels) get a 6-step tree each; the sequence W is
+//       and the set's total is  sum_w (a_w + 32 lb w W_w).
+//   level k >= 2 (msm_level_kernel): 32 consecutive items per wave.  Sequences that only need adding up
+//       (a, and the index-weighted sums v of the earlier levels) get a 5-step tree each; the sequence W is
 //       scanned and summed as above and yields v' = sum_l l W_l and W' = sum_l W_l for the next level.
 //       Independent waves (blockIdx.y) take the independent jobs.
 //   The last level leaves  F_0 = sum a,  F_1 .. F_L  (v of level 2 .. L + 1) per set; the powers of two that
-//   belong to them (64 lb, 64^2 lb, ..) are applied in the host fold, where a doubling costs well under 1 us.
-// 2^19 buckets, lb = 8: 16 + 16 dependent operations in level 1, 12 and 10 in the two small levels that follow
-// (before: 16 + 35 + 1, then two sum stages of 10).
-__global__ void __launch_bounds__(64) msm_bucket_wave_kernel(const u32x4* buckets, u32 nbuckets, u32 lb, u32 log_lb,
-                                                             u32 n1, u32 finalize, u32x4* out_a, u32x4* out_w) {
-  const u32 set = blockIdx.x / n1, w = blockIdx.x % n1, lane = threadIdx.x;
+//   belong to them (32 lb, 32^2 lb, ..) are applied in the host fold, where a doubling costs well under 1 us.
+__global__ void __launch_bounds__(64, 2) msm_bucket_wave_kernel(const u32x4* buckets, u32 nbuckets, u32 lb, u32 log_lb,
+                                                                u32 n1, u32 finalize, u32x4* out_a, u32x4* out_w) {
+  const u32 set = blockIdx.x / n1, w = blockIdx.x % n1;
+  const u32 pi = threadIdx.x >> 1;          // the pair's index in the wave: 32 chunks per wave
+  const bool isB = threadIdx.x & 1;
   const u32 nt = nbuckets / lb;  // chunks per set
-  const u32 t = 64 * w + lane;
-  Xyzz running = xyzz_identity(), sum = xyzz_identity();
+  const u32 t = GROUP * w + pi;
+  Half running = half_identity(), sum = half_identity();
   if (t < nt) {
     const u32x4* B = buckets + (size_t)16 * ((size_t)set * nbuckets + (size_t)t * lb);
     for (u32 i = lb; i-- > 0;) {
-      Xyzz b = ld_xyzz(B, i);
-      running = xyzz_add(running, b);
-      sum = xyzz_add(sum, running);
+      Half b = ld_half(B, i, isB);
+      running = half_add(running, b, isB);
+      sum = half_add(sum, running, isB);
     }
   }
-  for (int d = 1; d < 64; d <<= 1) {
-    Xyzz o = xyzz_shfl_down(running, d);
-    if (lane + d < 64) running = xyzz_add(running, o);
+  for (int d = 1; d < (int)GROUP; d <<= 1) {
+    Half o = half_shfl_down(running, d);
+    if (pi + d < GROUP) running = half_add(running, o, isB);
   }
-  if (lane == 0) st_xyzz(out_w, blockIdx.x, running);
-  if (lane == 0) running = xyzz_identity();
-  for (u32 k = 0; k < log_lb; ++k) running = xyzz_double(running);
-  sum = xyzz_add(sum, running);
-  for (int d = 32; d > 0; d >>= 1) {   // lanes >= d would add their own value to itself (the slow P + P path)
-    Xyzz o = xyzz_shfl_down(sum, d);
-    if (lane < (u32)d) sum = xyzz_add(sum, o);
+  if (pi == 0) {
+    st_half(out_w, blockIdx.x, running, isB);
+    running = half_identity();
   }
-  if (lane == 0) {
-    if (finalize && !sum.inf) {  // the host needs values that fit 384 bits
-      sum.x = fe_mul<FpP>(sum.x, fe_one<FpP>());
-      sum.y = fe_mul<FpP>(sum.y, fe_one<FpP>());
-    }
-    st_xyzz(out_a, blockIdx.x, sum);
+  for (u32 k = 0; k < log_lb; ++k) running = half_double(running, isB);
+  sum = half_add(sum, running, isB);
+  for (int d = GROUP / 2; d > 0; d >>= 1) {   // pairs >= d would add their own value to itself (the slow P + P path)
+    Half o = half_shfl_down(sum, d);
+    if (pi < (u32)d) sum = half_add(sum, o, isB);
+  }
+  if (pi == 0) {
+    if (finalize && !sum.inf) sum.c0 = fe_mul<FpP>(sum.c0, fe_one<FpP>());   // the host needs x, y that fit 384 bits
+    st_half(out_a, blockIdx.x, sum, isB);
   }
 }
 
@@ -504,42 +506,41 @@ struct LevelArgs {
   u32x4* w_out;             // sum_l W_l per group
   u32 n_plain;
   u32 n_items;
-  u32 n_groups;             // ceil(n_items / 64)
+  u32 n_groups;             // ceil(n_items / GROUP)
   u32 finalize;
 };
-__global__ void __launch_bounds__(64) msm_level_kernel(const LevelArgs a) {
-  const u32 set = blockIdx.x / a.n_groups, g = blockIdx.x % a.n_groups, job = blockIdx.y, lane = threadIdx.x;
-  const u32 idx = 64 * g + lane;
+__global__ void __launch_bounds__(64, 2) msm_level_kernel(const LevelArgs a) {
+  const u32 set = blockIdx.x / a.n_groups, g = blockIdx.x % a.n_groups, job = blockIdx.y;
+  const u32 pi = threadIdx.x >> 1;
+  const bool isB = threadIdx.x & 1;
+  const u32 idx = GROUP * g + pi;
   const bool live = idx < a.n_items;
   const size_t src = (size_t)set * a.n_items + idx;
-  Xyzz acc = xyzz_identity();
+  Half acc = half_identity();
   u32x4* out;
   if (job < a.n_plain) {
     const u32x4* in = job == 0 ? a.plain_in0 : (job == 1 ? a.plain_in1 : a.plain_in2);
     out = job == 0 ? a.plain_out0 : (job == 1 ? a.plain_out1 : a.plain_out2);
-    if (live) acc = ld_xyzz(in, src);
+    if (live) acc = ld_half(in, src, isB);
   } else {
     out = a.v_out;
-    if (live) acc = ld_xyzz(a.w_in, src);
-    for (int d = 1; d < 64; d <<= 1) {
-      Xyzz o = xyzz_shfl_down(acc, d);
-      if (lane + d < 64) acc = xyzz_add(acc, o);
+    if (live) acc = ld_half(a.w_in, src, isB);
+    for (int d = 1; d < (int)GROUP; d <<= 1) {
+      Half o = half_shfl_down(acc, d);
+      if (pi + d < GROUP) acc = half_add(acc, o, isB);
     }
-    if (lane == 0) {
-      st_xyzz(a.w_out, blockIdx.x, acc);
-      acc = xyzz_identity();
+    if (pi == 0) {
+      st_half(a.w_out, blockIdx.x, acc, isB);
+      acc = half_identity();
     }
   }
-  for (int d = 32; d > 0; d >>= 1) {
-    Xyzz o = xyzz_shfl_down(acc, d);
-    if (lane < (u32)d) acc = xyzz_add(acc, o);
+  for (int d = GROUP / 2; d > 0; d >>= 1) {
+    Half o = half_shfl_down(acc, d);
+    if (pi < (u32)d) acc = half_add(acc, o, isB);
   }
-  if (lane == 0) {
-    if (a.finalize && !acc.inf) {
-      acc.x = fe_mul<FpP>(acc.x, fe_one<FpP>());
-      acc.y = fe_mul<FpP>(acc.y, fe_one<FpP>());
-    }
-    st_xyzz(out, blockIdx.x, acc);
+  if (pi == 0) {
+    if (a.finalize && !acc.inf) acc.c0 = fe_mul<FpP>(acc.c0, fe_one<FpP>());
+    st_half(out, blockIdx.x, acc, isB);
   }
 }
 
@@ -661,23 +662,21 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   }
   const size_t l1_threads = (m + L1 - 1) / L1;
   const size_t total_buckets = (size_t)g.nbuckets * nsets_all;
-  // Buckets per thread in level 1 of the reduction (a power of two).  Level 1 keeps two accumulators and the
-  // loaded point in registers (256 VGPRs + 17 AGPRs: one wave per SIMD; forcing two spills and is slower:
-  // 938 vs 650 us), a lone wave issues one VALU instruction per ~7 cycles, and a thread does 2 LB + 16 + log2 LB
-  // group operations, so the time is (waves per SIMD, rounded up) x that count x ~13 us: the best LB leaves one
-  // wave per SIMD -- all buckets of the launch / 2^16: 8 for one MSM at 2^19 buckets, 32 for a batch of four, 1 for
-  // an 8-way shard with 2^15 buckets (profiles/r02_msm_lb.txt).
-  u32 lb_auto = 1;
+  // Buckets per lane pair in level 1 of the reduction (a power of two).  A pair does 2 LB + 11 + log2 LB group
+  // operations and the kernel fits two waves per SIMD (234 VGPRs), so the best LB is the one that fills the chip
+  // once: all buckets of the launch / 2^16 -- 8 for one MSM at 2^19 buckets, 32 for a batch of four -- and 2 for
+  // small sets (an 8-way shard with 2^15 buckets: 1.00 ms with 2, 1.05 ms with 1; profiles/r02_msm_lb.txt).
+  u32 lb_auto = 2;
   while (lb_auto < 64 && (total_buckets / lb_auto) > ((size_t)ctx->num_cus * 4 * 64)) lb_auto *= 2;
   const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : lb_auto, g.nbuckets);
   u32 log_lb = 0;
   while ((1u << log_lb) < LB) ++log_lb;
   const u32 chunks_per_win = g.nbuckets / LB;
   // waves per set in level 1, then the group counts of the follow-up levels (64 items per wave) down to one
-  const u32 n1 = (chunks_per_win + 63) / 64;
+  const u32 n1 = (chunks_per_win + GROUP - 1) / GROUP;
   std::vector<u32> lvl_groups;
   for (u32 items = n1; items > 1;) {
-    items = (items + 63) / 64;
+    items = (items + GROUP - 1) / GROUP;
     lvl_groups.push_back(items);
   }
   const u32 n_levels = (u32)lvl_groups.size();   // follow-up launches; the host receives n_levels + 1 points per set
@@ -813,7 +812,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
   }
   PM_HIP(ctx, hipGetLastError());
-  // 5 host fold: per set F_0 + 64 LB (F_1 + 64 (F_2 + 64 F_3)), then the windows
+  // 5 host fold: per set F_0 + 32 LB (F_1 + 32 (F_2 + 32 F_3)), then the windows
   PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)(n_levels + 1) * nsets_all * 256,
                              hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
@@ -821,7 +820,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   auto set_total = [&](size_t set) {
     XYZZ acc = xyzz_to_host(hw + 64 * ((size_t)n_levels * nsets_all + set));
     for (u32 k = n_levels; k-- > 0;) {
-      const u32 dbl = k == 0 ? 6 + log_lb : 6;
+      const u32 dbl = k == 0 ? 5 + log_lb : 5;   // log2(GROUP) per level
       for (u32 d = 0; d < dbl; ++d) acc = host::xyzz_double(acc);
       acc = host::xyzz_add(acc, xyzz_to_host(hw + 64 * ((size_t)k * nsets_all + set)));
     }
