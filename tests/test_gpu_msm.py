@@ -285,3 +285,34 @@ def test_fixed_base_edge_scalars(ctx, oracle):
     ident = np.zeros(12, np.uint64)
     ctx._check(ctx._lib.pm_g1_fixed_base_mul_dev(ctx._h, ident.ctypes.data_as(u64p), sc._p, len(ks), 0, out._p, None))
     assert not out.to_host().any()
+
+
+def test_reduction_meets_equal_and_opposite_sums(ctx, oracle):
+    """The bucket reduction adds bucket sums and running sums to each other: with bases drawn from
+    {G, -G, 2G, infinity} and tiny scalars, neighbouring buckets, chunks and waves hold EQUAL or OPPOSITE
+    points all the time, so the P + P (doubling) and P - P (identity) branches of the two-lane group law
+    (ec.cuh, half_add) run in the running sums, in the suffix scan and in the trees.  Both paths (per-call
+    bases and the window table), several chunk sizes."""
+    import plonk_prototype_amd as pa
+    rng = np.random.default_rng(2024)
+    g = oracle.g1_generator()
+    neg = g.copy()
+    y = limbs_to_ints(oracle.fp_from_mont(g[6:].reshape(1, 6)))[0]
+    neg[6:] = oracle.fp_to_mont(ints_to_limbs([B.P_MOD - y], 6))[0]
+    two = oracle.g1_add(g, g)
+    palette = np.stack([g, neg, two, np.zeros(12, np.uint64)])
+    try:
+        for trial in range(60):
+            n = int(rng.integers(2, 200))
+            pts = np.ascontiguousarray(palette[rng.integers(0, 4, n)])
+            top = [4, 16, 40, 1 << 13][trial % 4]
+            ks = [int(v) for v in rng.integers(0, top, n)]
+            sc = oracle.fr_to_mont(ints_to_limbs(ks, 4))
+            exp = oracle.g1_msm(pts, sc, SCALAR_MONTGOMERY, 4)
+            ctx.set_option("msm_lb", [0, 1, 2, 8][(trial // 4) % 4])
+            assert np.array_equal(gpu_msm_affine(ctx, pts, sc), exp), (trial, n, top)
+            if trial % 5 == 0:
+                bases = pa.host.Bases(ctx, pts).precompute([8, 13][trial % 2])
+                assert np.array_equal(pa.g1_to_affine(bases.msm(sc))[0], exp), (trial, n, top, "table")
+    finally:
+        ctx.set_option("msm_lb", 0)
