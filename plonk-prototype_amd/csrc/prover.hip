@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "context.h"
@@ -467,6 +468,46 @@ extern "C" int pm_plonk_key_commit_sharded(pm_ctx* ctx, pm_prover_key* key, cons
   return key_commit_impl(ctx, key, commit_key_slice, sh, transcript_label, verifier_key_out);
 }
 
+// pi_evals <- 0, then the sparse public inputs (a repeated position keeps its last value).  A handful goes up
+// element by element; longer lists are staged as compact (position, value) arrays in the round-2 scratch
+// (num / den are not written before round 2, which is ordered after this on the same stream) and scattered by
+// one kernel, so a statement with thousands of public inputs costs two copies, not thousands.
+__global__ void pi_scatter_kernel(const uint4* vals, const unsigned long long* pos, size_t cnt, uint4* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  out[2 * pos[i]] = vals[2 * i];
+  out[2 * pos[i] + 1] = vals[2 * i + 1];
+}
+static int scatter_public_inputs(pm_ctx* ctx, pm_prover_key* pk, const uint64_t* pos, const uint64_t* vals, size_t n_pi) {
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  PM_HIP(ctx, hipMemsetAsync(pk->pi_evals, 0, pk->n * 32, ctx->stream));
+  if (n_pi <= 16) {
+    for (size_t i = 0; i < n_pi; ++i)
+      PM_HIP(ctx, hipMemcpyAsync(at(pk->pi_evals, pos[i]), vals + 4 * i, 32, hipMemcpyHostToDevice, ctx->stream));
+    return PM_OK;
+  }
+  std::unordered_map<uint64_t, size_t> last;
+  last.reserve(2 * n_pi);
+  for (size_t i = 0; i < n_pi; ++i) last[pos[i]] = i;
+  std::vector<unsigned long long> hp;
+  std::vector<uint64_t> hv;
+  hp.reserve(last.size());
+  hv.reserve(4 * last.size());
+  for (size_t i = 0; i < n_pi; ++i) {
+    if (last[pos[i]] != i) continue;
+    hp.push_back(pos[i]);
+    hv.insert(hv.end(), vals + 4 * i, vals + 4 * i + 4);
+  }
+  const size_t cnt = hp.size();   // <= n: fits the n-element scratch arrays
+  PM_HIP(ctx, hipMemcpyAsync(pk->num, hv.data(), cnt * 32, hipMemcpyHostToDevice, ctx->stream));
+  PM_HIP(ctx, hipMemcpyAsync(pk->den, hp.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(pi_scatter_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint4*)pk->num, (const unsigned long long*)pk->den, cnt, (uint4*)pk->pi_evals);
+  PM_HIP(ctx, hipGetLastError());
+  PM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging vectors die with this scope
+  return PM_OK;
+}
+
 static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
                       const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
                       pm_plonk_proof* out);
@@ -532,8 +573,7 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   hipStream_t side = pk->side;
   void* pi_coeffs = at(pk->coeffs, 5 * n);
   {
-    PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, n, pk->pi_evals, nullptr));
-    for (size_t i = 0; i < n_pi; ++i) PK_TRY(pm_dev_upload(ctx, at(pk->pi_evals, pi_positions[i]), pi_values + 4 * i, 32));
+    PK_TRY(scatter_public_inputs(ctx, pk, pi_positions, pi_values, n_pi));
     PK_TRY(pm_fr_ntt_dev(ctx, pk->pi_evals, n, n, pi_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
     PK_TRY(pm_stream_fork(ctx, side, pk->ev_main));
     PK_TRY(pm_fr_ntt_dev(ctx, pk->coeffs, n, n, pk->coset, 4 * n, lg + 2, 4, PM_NTT_COSET, side));

@@ -306,6 +306,42 @@ def test_several_public_inputs(ctx, oracle):
         assert other.challenges["beta"] != proof.challenges["beta"]
 
 
+def test_many_public_inputs_take_the_scatter_path(ctx, oracle):
+    """More than 16 public inputs are staged and scattered by one kernel (csrc/prover.hip,
+    scatter_public_inputs): same proof as the oracle's with the dense vector; a repeated position keeps its last
+    value, exactly like the element-by-element path."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.field import fr_vec_from_limbs
+    n = 256
+    rows = tuple(range(0, n, 5))                                       # 52 public rows
+    circuit, wit, pi = pa.synthetic.chain_circuit(n, 77, public_rows=rows)
+    srs = _srs(oracle, n)
+    ck = pa.CommitKey(srs, ctx, precompute=True)
+    pk = PR.preprocess(circuit, ctx, ck)
+    proof = PR.prove(pk, ck, wit, pi)
+    pos, val = PR.sparse_public_inputs(pi)
+    assert len(pos) == len(rows) > 16
+    sel = {k: fr_vec_from_limbs(getattr(circuit, k)) if getattr(circuit, k) is not None else [0] * n for k in PO.SELECTORS}
+    wi, pii = [fr_vec_from_limbs(wit[j]) for j in range(4)], fr_vec_from_limbs(pi)
+    exp = PO.prove(n, sel, circuit.sigma_index.tolist(), wi, pii, proof.challenges)
+    assert {k: _ints(oracle, v)[0] for k, v in proof.evaluations.items()} == exp["evals"]
+    assert PR.check_identity(proof, n, B.horner(B.ifft(pii, 8), proof.challenges["z"]))
+    # position 10 given twice: a wrong value first, the right one last -> the same PI polynomial, hence the same
+    # round-1 commitments and a satisfied identity (the transcript differs: the list itself is bound)
+    wrong = val[2].copy()
+    wrong[0] ^= 1
+    pos2 = np.concatenate([pos[2:3], pos])
+    val2 = np.concatenate([wrong[None], val])
+    again = PR.prove(pk, ck, wit, (pos2, val2))
+    assert PR.check_identity(again, n, B.horner(B.ifft(pii, 8), again.challenges["z"]))
+    # ... and the other way round the identity breaks
+    pos3 = np.concatenate([pos, pos[2:3]])
+    val3 = np.concatenate([val, wrong[None]])
+    broken = PR.prove(pk, ck, wit, (pos3, val3))
+    assert not PR.check_identity(broken, n, B.horner(B.ifft(pii, 8), broken.challenges["z"]))
+
+
 def test_tampered_witness_fails_the_identity(ctx, oracle):
     import plonk_prototype_amd.prover as PR
     n = 64
