@@ -602,6 +602,9 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   PK_TRY(pm_fr_prefix_product_dev(ctx, pk->num, n, pk->den, nullptr));
   void* z_coeffs = at(pk->coeffs, 4 * n);
   PK_TRY(pm_fr_ntt_dev(ctx, pk->den, n, n, z_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
+  // z on the 4n coset depends on no further challenge: side stream, under the commitment to z
+  PK_TRY(pm_stream_fork(ctx, side, pk->ev_main));
+  PK_TRY(pm_fr_ntt_dev(ctx, z_coeffs, n, n, at(pk->coset, 4 * n * 4), 4 * n, lg + 2, 1, PM_NTT_COSET, side));
   PK_TRY(commit_batch(ctx, ck, shard, z_coeffs, n, n, 1, &out->commitments[4]));
   ts.append_commitment("z", out->commitments[4]);
   // ---- round 3 --------------------------------------------------------------------------------
@@ -610,8 +613,7 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   const HFr logic_sep = ts.challenge_scalar("logic separation challenge");
   const HFr fixed_sep = ts.challenge_scalar("fixed base separation challenge");
   const HFr var_sep = ts.challenge_scalar("variable base separation challenge");
-  PK_TRY(pm_fr_ntt_dev(ctx, z_coeffs, n, n, at(pk->coset, 4 * n * 4), 4 * n, lg + 2, 1, PM_NTT_COSET, nullptr));
-  PK_TRY(pm_stream_join(ctx, side, pk->ev_side));   // the wire / PI coset forms are ready
+  PK_TRY(pm_stream_join(ctx, side, pk->ev_side));   // the wire, PI and z coset forms are ready
   pm_plonk_quotient_args qa;
   memset(&qa, 0, sizeof qa);
   for (int j = 0; j < 4; ++j) {
