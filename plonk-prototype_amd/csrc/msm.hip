@@ -8,7 +8,7 @@
 //   1 msm_digits      scalar -> canonical integer -> signed c-bit digits; one (key, value)
 //                     pair per (window, point): key = window << (c-1) | (|d| - 1),
 //                     value = point index | sign << 31; zero digits get a trash key
-//   2 radix sort      pairs by key (hipcub DeviceRadixSort over key_bits) -> every bucket's
+//   2 radix sort      pairs by key (rocPRIM onesweep over key_bits, digit width chosen here) -> every bucket's
 //                     points are contiguous; the sum is order independent (exact group law)
 //   3 msm_accumulate  segmented reduction with a FIXED chunk of sorted entries per thread, so
 //                     load balance does not depend on the scalar distribution (all-equal
@@ -16,17 +16,20 @@
 //                     chunk go straight to their bucket, the head/tail runs of each chunk go
 //                     to a partial list that the same kernel shape reduces again (XYZZ inputs)
 //                     until one thread is left
-//   4 msm_bucket_reduce  per window: sum_b (b+1) B_b by chunked running sums + one small
-//                     scalar multiple per chunk, then a tree over the chunk results
-//   5 host            16-ish window sums (3.5 KiB) -> Horner fold with c doublings per window
-//                     and the final inversion on one CPU core (a serial chain of ~300 group
-//                     operations: ~0.2 ms on the host, several ms on a single GPU lane)
+//   4 msm_bucket_reduce  per bucket set: sum_b (b+1) B_b by running sums over a few buckets per lane
+//                     pair, a suffix scan and a tree across the wave, and two or three small levels
+//                     of the same shape (every point on two lanes: struct Half in ec.cuh)
+//   5 host            2-4 points per bucket set -> the powers of two of the reduction levels, the
+//                     Horner fold with c doublings per window (none with the window table) and
+//                     the final inversion on one CPU core (a serial chain of 20-300 group
+//                     operations: well under 0.2 ms on the host, several ms on a single GPU lane)
 //
 // Differences from the reference algorithm are confined to scheduling: signed digits (half
 // the buckets), a window width chosen for the GPU, sort + segmented sum instead of a serial
 // bucket loop.  The result is the same group element, returned in affine-normalised form.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -604,6 +607,27 @@ static XYZZ projective_to_xyzz(const uint64_t* xyz) {  // homogeneous (X/Z, Y/Z)
   return r;
 }
 
+// ------------------------------------------------------------------ 2: sort
+// rocPRIM's onesweep radix sort with the digit width picked for the key length: the tuned default sorts 8 bits per
+// pass, i.e. three passes for the 20-22 key bits of an MSM.  Measured on 13.6 M (u32 key, u32 value) pairs
+// (profiles/r02_sort_sweep.txt): 20 bits: 388 us default, 268 us with two 10-bit passes (1024 threads x 14 items);
+// 21-22 bits: 388 us default, 321 us with three 9-bit passes (1024 x 8), 342-357 us with two 11-bit passes.
+// Below rocPRIM's merge-sort limit (2^20 items) the configuration does not matter.
+using SortCfg10 = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 14>, rocprim::kernel_config<1024, 14>, 10,
+                                        rocprim::block_radix_rank_algorithm::match>>;
+using SortCfg9 = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
+                                        rocprim::block_radix_rank_algorithm::match>>;
+static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const u32* k_in, u32* k_out, const u32* v_in, u32* v_out, size_t m,
+                             u32 key_bits, hipStream_t st) {
+  if (key_bits <= 20) return rocprim::radix_sort_pairs<SortCfg10>(tmp, tmp_bytes, k_in, k_out, v_in, v_out, m, 0, key_bits, st);
+  if (key_bits <= 27) return rocprim::radix_sort_pairs<SortCfg9>(tmp, tmp_bytes, k_in, k_out, v_in, v_out, m, 0, key_bits, st);
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, m, 0, key_bits, st);
+}
+
 // ------------------------------------------------------------------ driver
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -684,8 +708,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
 
   // workspace layout
   size_t sort_tmp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const u32*)nullptr, (u32*)nullptr,
-                                     (const u32*)nullptr, (u32*)nullptr, (int)m, 0, (int)g.key_bits, st);
+  (void)sort_pairs(nullptr, sort_tmp, nullptr, nullptr, nullptr, nullptr, m, g.key_bits, st);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -731,8 +754,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   // 2 sort
   {
     ProfScope prof(ctx, st, "msm_sort_pairs");
-    PM_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sort_tmp, (const u32*)keys0, keys1,
-                                                   (const u32*)vals0, vals1, (int)m, 0, (int)g.key_bits, st));
+    PM_HIP(ctx, sort_pairs(ws + o_sort, sort_tmp, keys0, keys1, vals0, vals1, m, g.key_bits, st));
   }
   // 3 accumulate
   PM_HIP(ctx, hipMemsetAsync(buckets, 0, total_buckets * 256, st));
