@@ -91,22 +91,22 @@ PM_DEV Xyzz xyzz_madd(const Xyzz& acc, const Fp& x2, const Fp& y2) {
     return r;
   }
   Xyzz r;
-  Fp U2 = fe_mul<FpP>(x2, acc.zz);
-  Fp S2 = fe_mul<FpP>(y2, acc.zzz);
+  // five rounds of two independent products each (fe_mul2 / fe_sqr2: two dependent-mad chains per wave)
+  Fp U2, S2;
+  fe_mul2<FpP>(x2, acc.zz, y2, acc.zzz, U2, S2);
   Fp P = fe_norm<FpP>(fe_sub<FpP, 11, 1>(U2, acc.x));      // (1+, <13)
   Fp R = fe_norm<FpP>(fe_sub<FpP, 6, 1>(S2, acc.y));       // (1+, <8)
-  Fp PP = fe_sqr<FpP>(P);
-  Fp PPP = fe_mul<FpP>(P, PP);
-  Fp Q = fe_mul<FpP>(acc.x, PP);
-  Fp RR = fe_sqr<FpP>(R);
+  Fp PP, RR;
+  fe_sqr2<FpP>(P, R, PP, RR);
+  Fp PPP, Q;
+  fe_mul2<FpP>(P, PP, acc.x, PP, PPP, Q);
   Fp t = fe_sub<FpP, 3, 1>(RR, PPP);                       // (4, <5)
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
   Fp D = fe_sub<FpP, 11, 1>(Q, r.x);                       // (4, <13)
-  Fp YA = fe_mul<FpP>(R, D);
-  Fp YB = fe_mul<FpP>(acc.y, PPP);
+  Fp YA, YB;
+  fe_mul2<FpP>(R, D, acc.y, PPP, YA, YB);
   r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));           // (1+, <5)
-  r.zz = fe_mul<FpP>(acc.zz, PP);
-  r.zzz = fe_mul<FpP>(acc.zzz, PPP);
+  fe_mul2<FpP>(acc.zz, PP, acc.zzz, PPP, r.zz, r.zzz);
   r.inf = false;
   if (fp_is_zero_product(r.zz)) {  // same x: acc == +-(x2, y2)
     if (fp_is_zero_lazy(R))
@@ -122,24 +122,24 @@ PM_DEV Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
   if (a.inf) return b;
   if (b.inf) return a;
   Xyzz r;
-  Fp U1 = fe_mul<FpP>(a.x, b.zz);
-  Fp U2 = fe_mul<FpP>(b.x, a.zz);
-  Fp S1 = fe_mul<FpP>(a.y, b.zzz);
-  Fp S2 = fe_mul<FpP>(b.y, a.zzz);
+  Fp U1, U2, S1, S2;
+  fe_mul2<FpP>(a.x, b.zz, b.x, a.zz, U1, U2);
+  fe_mul2<FpP>(a.y, b.zzz, b.y, a.zzz, S1, S2);
   Fp P = fe_norm<FpP>(fe_sub<FpP, 3, 1>(U2, U1));          // (1+, <5)
   Fp R = fe_norm<FpP>(fe_sub<FpP, 3, 1>(S2, S1));          // (1+, <5)
-  Fp PP = fe_sqr<FpP>(P);
-  Fp PPP = fe_mul<FpP>(P, PP);
-  Fp Q = fe_mul<FpP>(U1, PP);
-  Fp RR = fe_sqr<FpP>(R);
+  Fp PP, RR;
+  fe_sqr2<FpP>(P, R, PP, RR);
+  Fp PPP, Q;
+  fe_mul2<FpP>(P, PP, U1, PP, PPP, Q);
   Fp t = fe_sub<FpP, 3, 1>(RR, PPP);
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
   Fp D = fe_sub<FpP, 11, 1>(Q, r.x);
-  Fp YA = fe_mul<FpP>(R, D);
-  Fp YB = fe_mul<FpP>(S1, PPP);
+  Fp YA, YB;
+  fe_mul2<FpP>(R, D, S1, PPP, YA, YB);
   r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));           // (1+, <5)
-  r.zz = fe_mul<FpP>(fe_mul<FpP>(a.zz, b.zz), PP);
-  r.zzz = fe_mul<FpP>(fe_mul<FpP>(a.zzz, b.zzz), PPP);
+  Fp z12, zzz12;
+  fe_mul2<FpP>(a.zz, b.zz, a.zzz, b.zzz, z12, zzz12);
+  fe_mul2<FpP>(z12, PP, zzz12, PPP, r.zz, r.zzz);
   r.inf = false;
   if (fp_is_zero_product(r.zz)) {
     if (fp_is_zero_lazy(R))
@@ -201,9 +201,9 @@ PM_DEV Half half_double(const Half& p, bool isB) {
   const Fp s2 = fe_mul<FpP>(t, fp_select(isB, s1, s1o));    // A: S = x V;  B: W = U V
   const Fp xx = fp_select(isB, s1o, s1);
   const Fp M = fe_add<FpP>(fe_add<FpP>(xx, xx), xx);        // (3, <6) on both lanes
-  const Fp s3 = fe_mul<FpP>(fp_select(isB, s2, M), fp_select(isB, p.c0, M));   // A: MM;  B: YB = W y
   Half r;
-  r.c1 = fe_mul<FpP>(fp_select(isB, s2, s1o), p.c1);        // A: ZZ3 = V zz;  B: ZZZ3 = W zzz
+  Fp s3;                                                    // A: MM;  B: YB = W y   | two chains per wave:
+  fe_mul2<FpP>(fp_select(isB, s2, M), fp_select(isB, p.c0, M), fp_select(isB, s2, s1o), p.c1, s3, r.c1);   // A: ZZ3 = V zz;  B: ZZZ3 = W zzz
   const Fp x3 = fe_norm<FpP>(fe_sub<FpP, 5, 1>(s3, fe_add<FpP>(s2, s2)));      // A: X3 (1+, <7); B: unused
   const Fp D = fe_sub<FpP, 8, 1>(s2, x3);                   // (4, <10)
   const Fp ya = fe_mul<FpP>(M, D);                          // A: YA
@@ -216,22 +216,23 @@ PM_DEV Half half_double(const Half& p, bool isB) {
 PM_DEV Half half_add(const Half& a, const Half& b, bool isB) {
   if (a.inf) return b;
   if (b.inf) return a;
-  const Fp m1 = fe_mul<FpP>(a.c0, b.c1);                    // A: U1 = X1 ZZ2;   B: S1 = Y1 ZZZ2
-  const Fp m2 = fe_mul<FpP>(b.c0, a.c1);                    // A: U2;            B: S2
+  // products in rounds of two independent ones where the formulas allow it (fe_mul2: two chains per wave)
+  Fp m1, m2;                                                // A: U1 = X1 ZZ2, U2 = X2 ZZ1;   B: S1 = Y1 ZZZ2, S2 = Y2 ZZZ1
+  fe_mul2<FpP>(a.c0, b.c1, b.c0, a.c1, m1, m2);
   const Fp d = fe_norm<FpP>(fe_sub<FpP, 3, 1>(m2, m1));     // A: P;  B: R   (1+, <5)
-  const Fp e = fe_sqr<FpP>(d);                              // A: PP; B: RR
+  Fp e, z12;                                                // A: PP, ZZ1 ZZ2;  B: RR, ZZZ1 ZZZ2
+  fe_mul2<FpP>(d, d, a.c1, b.c1, e, z12);
   const Fp dO = fp_pair_swap(d);                            // A: R;  B: P
   const Fp eO = fp_pair_swap(e);                            // A: RR; B: PP
-  const Fp z12 = fe_mul<FpP>(a.c1, b.c1);                   // A: ZZ1 ZZ2;  B: ZZZ1 ZZZ2
   const Fp f = fe_mul<FpP>(fp_select(isB, dO, m1), fp_select(isB, eO, e));   // A: Q = U1 PP;  B: PPP = P PP
   const Fp fO = fp_pair_swap(f);                            // A: PPP;  B: Q
   Half r;
-  r.c1 = fe_mul<FpP>(z12, fp_select(isB, f, e));            // A: ZZ3 = ZZ1 ZZ2 PP;  B: ZZZ3 = ZZZ1 ZZZ2 PPP
   const Fp rr = fp_select(isB, e, eO), ppp = fp_select(isB, f, fO), q = fp_select(isB, fO, f);
   const Fp t = fe_sub<FpP, 3, 1>(rr, ppp);                  // (4, <5)
   const Fp x3 = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(q, q)));   // (1+, <10), both lanes
   const Fp D = fe_sub<FpP, 11, 1>(q, x3);                   // (4, <13)
-  const Fp h = fe_mul<FpP>(fp_select(isB, m1, dO), fp_select(isB, f, D));   // A: YA = R D;  B: YB = S1 PPP
+  Fp h;                                                     // A: ZZ3 = ZZ1 ZZ2 PP, YA = R D;  B: ZZZ3 = ZZZ1 ZZZ2 PPP, YB = S1 PPP
+  fe_mul2<FpP>(z12, fp_select(isB, f, e), fp_select(isB, m1, dO), fp_select(isB, f, D), r.c1, h);
   const Fp hO = fp_pair_swap(h);                            // B: YA
   r.c0 = fp_select(isB, fe_norm<FpP>(fe_sub<FpP, 3, 1>(hO, h)), x3);
   r.inf = false;

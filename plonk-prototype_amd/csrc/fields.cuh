@@ -287,6 +287,125 @@ PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
   return t;
 }
 
+// Two independent products / squarings in lock step: the same arithmetic as fe_mul / fe_sqr, the statements of
+// the two interleaved column by column.  A column is a chain of dependent v_mad_u64_u32 (result latency ~3
+// issue slots) and the wave issues in order: one product alone leaves the SIMD idle between dependent
+// instructions unless other waves fill in -- kernels that run one or two waves per SIMD (the MSM's) want two
+// chains per wave (measured: DESIGN.md section 4).
+template <class P>
+PM_DEV void fe_mul2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, Fe<P>& r0, Fe<P>& r1) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q0[N], q1[N];
+  u64 acc0 = 0, acc1 = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      acc0 += (u64)a0.l[i] * b0.l[k - i];
+      acc1 += (u64)a1.l[i] * b1.l[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) {
+      acc0 += (u64)q0[i] * M.v[k - i];
+      acc1 += (u64)q1[i] * M.v[k - i];
+    }
+    if (M.v[0] == 1u) {
+      q0[k] = (0u - (u32)acc0) & MASK;
+      q1[k] = (0u - (u32)acc1) & MASK;
+      acc0 += q0[k];
+      acc1 += q1[k];
+    } else {
+      q0[k] = ((u32)acc0 * NINV) & MASK;
+      q1[k] = ((u32)acc1 * NINV) & MASK;
+      acc0 += (u64)q0[k] * M.v[0];
+      acc1 += (u64)q1[k] * M.v[0];
+    }
+    acc0 >>= W;
+    acc1 >>= W;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      acc0 += (u64)a0.l[i] * b0.l[k - i];
+      acc1 += (u64)a1.l[i] * b1.l[k - i];
+    }
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      acc0 += (u64)q0[i] * M.v[k - i];
+      acc1 += (u64)q1[i] * M.v[k - i];
+    }
+    r0.l[k - N] = (u32)acc0 & MASK;
+    r1.l[k - N] = (u32)acc1 & MASK;
+    acc0 >>= W;
+    acc1 >>= W;
+  }
+  r0.l[N - 1] = (u32)acc0;
+  r1.l[N - 1] = (u32)acc1;
+}
+template <class P>
+PM_DEV void fe_sqr2(const Fe<P>& a0, const Fe<P>& a1, Fe<P>& r0, Fe<P>& r1) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q0[N], q1[N], d0[N], d1[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    d0[i] = a0.l[i] << 1;
+    d1[i] = a1.l[i] << 1;
+  }
+  u64 acc0 = 0, acc1 = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int j = k - i;
+      if (j < 0 || j >= N || i > j) continue;
+      if (i == j) {
+        acc0 += (u64)a0.l[i] * a0.l[i];
+        acc1 += (u64)a1.l[i] * a1.l[i];
+      } else {
+        acc0 += (u64)a0.l[i] * d0[j];
+        acc1 += (u64)a1.l[i] * d1[j];
+      }
+    }
+    if (k < N) {
+#pragma unroll
+      for (int i = 0; i < k; ++i) {
+        acc0 += (u64)q0[i] * M.v[k - i];
+        acc1 += (u64)q1[i] * M.v[k - i];
+      }
+      if (M.v[0] == 1u) {
+        q0[k] = (0u - (u32)acc0) & MASK;
+        q1[k] = (0u - (u32)acc1) & MASK;
+        acc0 += q0[k];
+        acc1 += q1[k];
+      } else {
+        q0[k] = ((u32)acc0 * NINV) & MASK;
+        q1[k] = ((u32)acc1 * NINV) & MASK;
+        acc0 += (u64)q0[k] * M.v[0];
+        acc1 += (u64)q1[k] * M.v[0];
+      }
+    } else {
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i) {
+        acc0 += (u64)q0[i] * M.v[k - i];
+        acc1 += (u64)q1[i] * M.v[k - i];
+      }
+      r0.l[k - N] = (u32)acc0 & MASK;
+      r1.l[k - N] = (u32)acc1 & MASK;
+    }
+    acc0 >>= W;
+    acc1 >>= W;
+  }
+  r0.l[N - 1] = (u32)acc0;
+  r1.l[N - 1] = (u32)acc1;
+}
+
 // Cheap reduction without a Montgomery product: x (limbs < 2^32, value < 2^(W N)) -> normalised
 // limbs, same residue, value < m + m/2^16.  One-limb Barrett: q = floor(top(x) / (top(m)+1)) never
 // exceeds floor(x/m) and misses it by at most one; x - q m is formed as the low W N bits of
