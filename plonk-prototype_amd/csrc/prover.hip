@@ -565,7 +565,7 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
       ts.append_scalar("pi", get(pi_values + 4 * i));
     }
   }
-  const HFr one = fone(), zero = pm::host::zero<4>();
+  const HFr one = fone();
   // ---- round 1 --------------------------------------------------------------------------------
   PK_TRY(pm_fr_ntt_dev(ctx, d_witness, n, n, pk->coeffs, n, lg, 4, PM_NTT_INVERSE, nullptr));
   // work no challenge depends on goes to the side stream and runs under the MSMs of rounds 1 and 2:
