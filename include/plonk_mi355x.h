@@ -116,6 +116,20 @@ int pm_fr_ntt_dev(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride
                   size_t out_stride, uint32_t log_n, uint32_t batch, uint32_t flags,
                   void* hip_stream);
 
+/* One 2^log_n-point transform whose vector is block-distributed in natural order over `world` ranks (one
+ * process and one context per GPU): rank r passes its N/world elements in d_inout
+ * (DEVICE memory, transformed in place: the rank's block of x -> the same block of the result) and a scratch
+ * buffer d_stage of 2 N/world elements (N/world when world == 1).  Four-step decomposition with three all-to-all
+ * transposes; the sub-transforms are the library's own batched passes and the result equals pm_fr_ntt_dev's bit
+ * for bit.  `exchange` performs the all-to-all of equal blocks (block p of d_send goes to rank p, block p of
+ * d_recv comes from rank p; it is called with the library's stream idle and must return with the data in place;
+ * non-zero = failure); NULL uses the context's RCCL communicator (pm_comm_init) on the context's stream.
+ * world must be a power of two dividing both 2^(log_n / 2) and 2^(log_n - log_n / 2); 2 <= log_n <= 26.
+ * Runs on the context's own stream.  Mirrors nothing upstream: dusk-plonk is single-device. */
+typedef int (*pm_alltoall_fn)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
+int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t log_n, uint32_t world,
+                           uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user);
+
 /* ---- KZG commit: G1 MSM ---------------------------------------------------------------- */
 
 /* Upload n affine bases (CommitKey::powers_of_g) once; they stay resident in HBM. */

@@ -39,6 +39,7 @@ class PlonkProof(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint32)
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 VK_POINTS = (C.c_uint64 * 12) * 15
 PLONK_SELECTORS, PLONK_PROOF_BYTES, PLONK_BIND_PUBLIC_INPUTS = 11, 1040, 1
 COMM_ID_BYTES, COMM_MAX_POINTS = 128, 16
@@ -58,6 +59,8 @@ SIGNATURES = {
                                   C.c_uint32, C.c_uint32, C.c_uint32]),
     "pm_fr_ntt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                 C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "pm_fr_ntt_fourstep_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_void_p, C.c_void_p]),
     "pm_g1_bases_upload": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pm_g1_bases_from_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pm_g1_fixed_base_mul_dev": (C.c_int, [C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,

@@ -122,30 +122,30 @@ extern "C" int pm_init(int device_id, pm_ctx** out) {
 extern "C" void pm_shutdown(pm_ctx* ctx) {
   if (!ctx) return;
   (void)pm_comm_destroy(ctx);
-  hipSetDevice(ctx->device);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
   for (int d = 0; d < 2; ++d) {
-    for (auto& kv : ctx->step_tw[d]) hipFree(kv.second);
-    for (auto& kv : ctx->step4_tw[d]) hipFree(kv.second);
+    for (auto& kv : ctx->step_tw[d]) (void)hipFree(kv.second);
+    for (auto& kv : ctx->step4_tw[d]) (void)hipFree(kv.second);
     for (auto& kv : ctx->domain[d]) {
-      hipFree(kv.second.tw_hi);
-      hipFree(kv.second.tw_lo);
-      hipFree(kv.second.cs_hi);
-      hipFree(kv.second.cs_lo);
-      for (void* t : kv.second.pass_tw) hipFree(t);
+      (void)hipFree(kv.second.tw_hi);
+      (void)hipFree(kv.second.tw_lo);
+      (void)hipFree(kv.second.cs_hi);
+      (void)hipFree(kv.second.cs_lo);
+      for (void* t : kv.second.pass_tw) (void)hipFree(t);
     }
   }
   for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws,
                           &ctx->msm_scalars, &ctx->poly_ws, &ctx->poly_tab})
-    if (b->ptr) hipFree(b->ptr);
-  if (ctx->msm_host_pinned) hipHostFree(ctx->msm_host_pinned);
+    if (b->ptr) (void)hipFree(b->ptr);
+  if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
   for (StreamOrder* o : {&ctx->ord_ntt, &ctx->ord_msm, &ctx->ord_poly})
     if (o->ev) (void)hipEventDestroy(o->ev);
   prof_collect(ctx);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
-  if (ctx->copy_in) hipStreamDestroy(ctx->copy_in);
-  if (ctx->copy_out) hipStreamDestroy(ctx->copy_out);
-  hipStreamDestroy(ctx->stream);
+  if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+  if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
+  (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 

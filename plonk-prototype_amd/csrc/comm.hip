@@ -26,8 +26,13 @@ struct Rccl {
   int (*CommInitRank)(void**, int, ncclUniqueIdRaw, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int /* ncclDataType_t */, void*, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int /* peer */, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int /* peer */, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
+  bool p2p() const { return Send && Recv && GroupStart && GroupEnd; }
 };
 static Rccl& rccl() {
   static Rccl r;
@@ -42,10 +47,15 @@ static Rccl& rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
   });
   return r;
 }
+static const int kNcclUint8 = 1;
 static const int kNcclUint64 = 5;   // ncclUint64 (nccl.h / rccl.h: int8 0, uint8 1, int32 2, uint32 3, int64 4, uint64 5)
 
 // message of one rank: [count | PM_COMM_MAX_POINTS x 18 limbs]; count = 0 is the abort marker of a rank
@@ -63,6 +73,24 @@ int fold_gathered(const uint64_t* msgs, int world, uint32_t k_local, uint64_t* o
     int rc = pm_g1_fold(parts.data(), (size_t)world, out_xyz + 18 * (size_t)j);
     if (rc) return rc;
   }
+  return PM_OK;
+}
+
+// All-to-all of equal blocks on the context's communicator and the given stream: block p of `send` goes to
+// rank p, block p of `recv` comes from rank p (grouped ncclSend / ncclRecv: one direct xGMI transfer per peer).
+// The caller holds no lock that the stream's earlier work needs.  Used by the rank-split NTT (ntt.hip).
+int comm_alltoall(pm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer, hipStream_t st) {
+  if (!ctx->comm) return set_err(ctx, PM_ERR_EXCHANGE, "no communicator: pm_comm_init first");
+  Rccl& r = rccl();
+  if (!r.p2p()) return set_err(ctx, PM_ERR_EXCHANGE, "librccl has no ncclSend / ncclRecv");
+  int nrc = r.GroupStart();
+  for (int p = 0; p < ctx->comm_world && nrc == 0; ++p) {
+    nrc = r.Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclUint8, p, ctx->comm, st);
+    if (nrc == 0) nrc = r.Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclUint8, p, ctx->comm, st);
+  }
+  const int erc = r.GroupEnd();
+  if (nrc == 0) nrc = erc;
+  if (nrc != 0) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclSend/ncclRecv: ") + r.GetErrorString(nrc));
   return PM_OK;
 }
 

@@ -114,6 +114,7 @@ struct ProfScope {
 };
 int prof_collect(pm_ctx* ctx);
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
+int comm_alltoall(pm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer, hipStream_t st);   // comm.hip
 int order_on(pm_ctx* ctx, StreamOrder& o, hipStream_t st);
 
 #define PM_HIP(ctx, call)                                                                   \

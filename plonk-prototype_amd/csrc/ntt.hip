@@ -574,3 +574,151 @@ extern "C" int pm_fr_ntt(pm_ctx* ctx, const uint64_t* in, size_t in_len, uint64_
   return pm_fr_ntt_batch(ctx, in, in_len, in_len, out, (size_t)1 << (log_n < 32 ? log_n : 0), log_n,
                          1, flags);
 }
+
+// ------------------------------------------------------------------ N5: one transform split over ranks
+// SURVEY.md section 8e row 3 / 8f N5.  The vector of a 2^log_n-point transform is block-distributed in natural
+// order over `world` ranks (one process and one pm_ctx per GPU): rank r holds x[r N/W, (r+1) N/W) and receives the
+// same block of the result.  N = N1 N2 as an N1 x N2 row-major matrix (N1 = 2^(log_n / 2)):
+//     transpose (all-to-all) -> N2/W batched transforms of size N1 -> twiddles w_N^(j k1)
+//     -> transpose -> N1/W batched transforms of size N2 -> transpose (natural order)
+// A transpose is: pack this rank's [R_loc][C] slice into per-peer blocks [peer][C/W][R_loc] (a 32 x 32 tile
+// transpose through LDS; the twiddle / coset factors are folded into this pass), one all-to-all of N/W^2-element
+// blocks (the context's RCCL communicator: grouped ncclSend / ncclRecv, one direct xGMI transfer per peer -- or a
+// caller-supplied callback), and an unpack that interleaves what the peers sent into [C/W][R].  The sub-transforms
+// are the library's own batched passes.  Results are identical to the single-GPU plan bit for bit.
+namespace pm {
+
+struct FsMul {            // factor applied to element (row a, column b) of the slice while it is packed / unpacked
+  u32 mode;               // 0 none, 1 table^((row0 + a) * b)  (twiddle), 2 table^((row0 + a) * C + b)  (coset by index)
+  const u32x4* hi;
+  const u32x4* lo;
+  u32 lh;
+  u32 row0;
+};
+PM_DEV void fs_apply(u32x4& v0, u32x4& v1, const FsMul& m, u32 a, u32 b, u32 C) {
+  if (m.mode == 0) return;
+  const u32 e = m.mode == 1 ? (m.row0 + a) * b : (m.row0 + a) * C + b;
+  u32x4 raw[2] = {v0, v1};
+  Fr x = fe_load<FrP>(raw);
+  x = fe_mul<FrP>(x, two_level(m.hi, m.lo, e, m.lh));
+  fe_store<FrP>(raw, x);
+  v0 = raw[0];
+  v1 = raw[1];
+}
+// send[(s * Cw + bl) * R_loc + a] = f(src[a * C + s * Cw + bl]),  s = b / Cw, bl = b % Cw
+__global__ void __launch_bounds__(256) fs_pack_kernel(const u32x4* src, u32 R_loc, u32 C, u32 Cw, u32x4* send, const FsMul m) {
+  __shared__ u32x4 t0[32][33], t1[32][33];
+  const u32 a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  const u32 tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;   // 32 x 8
+  for (u32 r = ty; r < 32; r += 8) {
+    const u32 a = a0 + r, b = b0 + tx;
+    if (a < R_loc && b < C) {
+      u32x4 v0 = src[2 * ((size_t)a * C + b)], v1 = src[2 * ((size_t)a * C + b) + 1];
+      fs_apply(v0, v1, m, a, b, C);
+      t0[r][tx] = v0;
+      t1[r][tx] = v1;
+    }
+  }
+  __syncthreads();
+  for (u32 r = ty; r < 32; r += 8) {
+    const u32 b = b0 + r, a = a0 + tx;
+    if (a < R_loc && b < C) {
+      const u32 s = b / Cw, bl = b % Cw;
+      const size_t o = ((size_t)s * Cw + bl) * R_loc + a;
+      send[2 * o] = t0[tx][r];
+      send[2 * o + 1] = t1[tx][r];
+    }
+  }
+}
+// dst[bl * R + p * R_loc + a] = g(recv[(p * Cw + bl) * R_loc + a]),  R = W R_loc; g's index: row bl, column p R_loc + a
+__global__ void __launch_bounds__(256) fs_unpack_kernel(const u32x4* recv, u32 R_loc, u32 W, u32 Cw, u32x4* dst, const FsMul m) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 R = R_loc * W;
+  if (t >= (size_t)Cw * R) return;
+  const u32 bl = (u32)(t / R), rr = (u32)(t % R), p = rr / R_loc, a = rr % R_loc;
+  const size_t i = ((size_t)p * Cw + bl) * R_loc + a;
+  u32x4 v0 = recv[2 * i], v1 = recv[2 * i + 1];
+  fs_apply(v0, v1, m, bl, rr, R);
+  dst[2 * t] = v0;
+  dst[2 * t + 1] = v1;
+}
+
+}  // namespace pm
+
+extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t log_n, uint32_t world,
+                                      uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user) {
+  if (!ctx || !d_inout || !d_stage) return PM_ERR_BAD_ARG;
+  if (world == 0 || (world & (world - 1)) || rank >= world) return PM_ERR_BAD_ARG;
+  if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET)) return PM_ERR_BAD_ARG;
+  if (log_n < 2 || log_n > 26) return PM_ERR_DOMAIN_TOO_LARGE;   // 32-bit exponents of the two-level tables
+  const uint32_t l1 = log_n / 2, l2 = log_n - l1;
+  const uint32_t n1 = 1u << l1, n2 = 1u << l2;
+  if (n1 % world || n2 % world) return PM_ERR_BAD_ARG;            // the ranks must divide both factors
+  const bool inverse = flags & PM_NTT_INVERSE, coset = flags & PM_NTT_COSET;
+  const size_t blk = ((size_t)1 << log_n) / world;                // elements per rank
+  u32x4* x = (u32x4*)d_inout;
+  u32x4* send = (u32x4*)d_stage;
+  u32x4* recv = world == 1 ? send : send + 2 * blk;
+  hipStream_t st;
+  NttDomainTables* dt = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    st = ctx->stream;
+    if (world > 1 && !exchange && (!ctx->comm || ctx->comm_world != (int)world || ctx->comm_rank != (int)rank))
+      return set_err(ctx, PM_ERR_EXCHANGE, "no exchange callback and no matching communicator (pm_comm_init)");
+    int rc = order_on(ctx, ctx->ord_ntt, st);
+    if (!rc) rc = get_domain_tables(ctx, inverse ? 1 : 0, log_n, coset, &dt, st);
+    if (rc) return rc;
+  }
+  const FsMul none{0, nullptr, nullptr, 0, 0};
+  // one transpose: slice [R_loc][C] of a row-distributed [R][C] matrix -> slice [C / W][R] of its transpose
+  auto transpose = [&](u32 R_loc, u32 C, const FsMul& on_pack, const FsMul& on_unpack) -> int {
+    const u32 Cw = C / world;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      ProfScope prof(ctx, st, "ntt_fourstep_transpose");
+      hipLaunchKernelGGL(fs_pack_kernel, dim3((C + 31) / 32, (R_loc + 31) / 32), dim3(256), 0, st, (const u32x4*)x, R_loc, C, Cw,
+                         send, on_pack);
+      PM_HIP(ctx, hipGetLastError());
+      if (world > 1 && !exchange) {
+        int rc = comm_alltoall(ctx, send, recv, (size_t)Cw * R_loc * 32, st);
+        if (rc) return rc;
+      }
+    }
+    if (world > 1 && exchange) {   // the callback sees finished data and returns when the peers' blocks are in place
+      {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        PM_HIP(ctx, hipStreamSynchronize(st));
+      }
+      if (exchange(user, send, recv, (size_t)Cw * R_loc * 32) != 0) return set_err(ctx, PM_ERR_EXCHANGE, "the all-to-all callback failed");
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ProfScope prof(ctx, st, "ntt_fourstep_transpose");
+    const size_t total = (size_t)Cw * R_loc * world;
+    hipLaunchKernelGGL(fs_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u32x4*)recv, R_loc, world,
+                       Cw, x, on_unpack);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+  };
+  const uint32_t sub = inverse ? PM_NTT_INVERSE : 0;
+  // 1: [N1/W][N2] -> [N2/W][N1]  (coset_fft: x[n] *= g^n on the way out)
+  FsMul pre = none;
+  if (coset && !inverse) pre = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (n1 / world)};
+  int rc = transpose(n1 / world, n2, pre, none);
+  if (rc) return rc;
+  // 2: N2/W transforms of size N1 over the columns
+  rc = pm_fr_ntt_dev(ctx, x, n1, n1, x, n1, l1, n2 / world, sub, nullptr);
+  if (rc) return rc;
+  // 3: [N2/W][N1] -> [N1/W][N2], element (j, k1) times w^(j k1) on the way out
+  const FsMul tw{1, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, rank * (n2 / world)};
+  rc = transpose(n2 / world, n1, tw, none);
+  if (rc) return rc;
+  // 4: N1/W transforms of size N2 over the rows
+  rc = pm_fr_ntt_dev(ctx, x, n2, n2, x, n2, l2, n1 / world, sub, nullptr);
+  if (rc) return rc;
+  // 5: [N1/W][N2] (k1, k2) -> [N2/W][N1] (k2, k1) = natural order  (coset_ifft: X[k] *= g^-k on the way in)
+  FsMul post = none;
+  if (coset && inverse) post = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (n2 / world)};
+  return transpose(n1 / world, n2, none, post);
+}

@@ -118,44 +118,26 @@ class ShardedCommitKey:
 
 
 # ---------------------------------------------------------------------------------------------
-# One NTT split over the GPUs of a node: the four-step
-# decomposition with the matrix distributed by rows and all-to-all transposes between the steps.
-def _transpose_exchange(t, rows: int, cols: int, world: int):
-    """t: this rank's [rows/world, cols, 4] slice of a row-distributed [rows, cols] matrix of Fr.
-    Returns this rank's [cols/world, rows, 4] slice of the transposed matrix (one all_to_all)."""
-    import torch
-    import torch.distributed as dist
-
-    if world == 1:
-        return t.transpose(0, 1).contiguous()
-    rl, cl = rows // world, cols // world
-    send = t.view(rl, world, cl, 4).permute(1, 0, 2, 3).contiguous()        # [dest][row_local][col_local]
-    recv = torch.empty_like(send)
-    if send.is_cuda and dist.get_backend() != "nccl":                        # gloo rehearsal: exchange on the host
-        s, r = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
-        dist.all_to_all_single(r, s)
-        recv.copy_(r)
-    else:
-        dist.all_to_all_single(recv, send)
-    return recv.view(rows, cl, 4).transpose(0, 1).contiguous()               # [col_local][row]
-
-
+# One NTT split over the GPUs of a node: the four-step decomposition with
+# the matrix distributed by rows and all-to-all transposes between the steps, NATIVE in the library
+# (pm_fr_ntt_fourstep_dev, csrc/ntt.hip: pack / unpack kernels, the library's batched passes, RCCL
+# ncclSend / ncclRecv).  This class only owns the staging tensor and, for process groups the library cannot
+# drive itself (gloo rehearsals), the all-to-all callback over torch.distributed.
 class FourStepNTT:
     """A 2^log_n-point NTT whose vector is block-distributed in natural order over the ranks of the
     default process group: rank r holds x[r N/W, (r+1) N/W) on its GPU, and receives the same block
-    of the result.  N = N1 N2 as an N1 x N2 row-major matrix:
+    of the result (bit-identical to the single-GPU plan).  N = N1 N2 as an N1 x N2 row-major matrix:
 
         transpose (all-to-all) -> N2/W batched NTTs of size N1 -> twiddles w_N^(j k1)
         -> transpose -> N1/W batched NTTs of size N2 -> transpose (natural order)
 
     Each all-to-all moves (W-1)/W of the rank's 32 N / W bytes; over RCCL that is one direct xGMI
-    transfer per peer.  Local transforms are the library's batched NTT kernels; transposes inside a
-    rank are strided copies.  Needs W | N1 and W | N2.  Twiddle rows are cached per (log_n, direction)."""
+    transfer per peer.  Needs W | N1 and W | N2.  ``native_comm=True`` uses the context's own RCCL
+    communicator (``Context.comm_init``); otherwise the exchange runs through torch.distributed."""
 
-    def __init__(self, ctx: Context, log_n: int):
+    def __init__(self, ctx: Context, log_n: int, native_comm: bool = False):
         import torch.distributed as dist
-        from .host import domain_info
-        self.ctx, self.log_n = ctx, log_n
+        self.ctx, self.log_n, self.native_comm = ctx, log_n, native_comm
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.l1 = log_n // 2
@@ -163,66 +145,46 @@ class FourStepNTT:
         self.n1, self.n2 = 1 << self.l1, 1 << self.l2
         if self.n1 % self.world or self.n2 % self.world:
             raise Error(_lib.PM_ERR_BAD_ARG, "the number of ranks must divide both factors of the transform")
-        self.omega, self.omega_inv, self.size_inv = domain_info(log_n)
-        self._tw = {}
+        self._stage = None
+        self._cb = None
 
-    def _twiddles(self, inverse: bool, like):
-        """[N2/W, N1, 4]: row j_local holds w^((j0 + j_local) k1), k1 < N1 (w^-1 for the inverse)."""
+    def _exchange_callback(self, stage):
+        """ALLTOALL_FN over torch.distributed on the two halves of ``stage`` (the library passes their addresses)."""
         import torch
-        from .field import R_MOD, fr_from_limbs, fr_to_limbs
-        if inverse not in self._tw:
-            cl = self.n2 // self.world
-            t = torch.empty((cl, self.n1, 4), dtype=torch.int64, device=like.device)
-            w = fr_from_limbs(self.omega_inv if inverse else self.omega)
-            one = fr_to_limbs(1)
-            for jl in range(cl):
-                base = fr_to_limbs(pow(w, self.rank * cl + jl, R_MOD))
-                self.ctx.fr_powers(base, one, self.n1, t[jl].data_ptr())
-            self.ctx.sync()
-            self._tw[inverse] = t
-        return self._tw[inverse]
+        import torch.distributed as dist
+        blk = stage.shape[0] // 2
+        send, recv = stage[:blk], stage[blk:]
 
-    def _coset(self, x, inverse: bool):
-        """x[n] *= 7^n (forward, before) or X[k] *= 7^-k (inverse, after) on this rank's block."""
-        import torch
-        from .field import GENERATOR, R_MOD, fr_to_limbs
-        blk = x.shape[0]
-        g = pow(GENERATOR, -1, R_MOD) if inverse else GENERATOR
-        p = torch.empty_like(x)
-        self.ctx.fr_powers(fr_to_limbs(g), fr_to_limbs(pow(g, self.rank * blk, R_MOD)), blk, p.data_ptr())
-        self.ctx.fr_vec_op(2, x.data_ptr(), p.data_ptr(), blk, x.data_ptr(), blk)
-        self.ctx.sync()
-        return x
+        def cb(_user, d_send, d_recv, _bytes_per_peer):
+            try:
+                if d_send != send.data_ptr() or d_recv != recv.data_ptr():
+                    return 1
+                if dist.get_backend() != "nccl":                      # gloo rehearsal: exchange on the host
+                    s, r = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+                    dist.all_to_all_single(r, s)
+                    recv.copy_(r)
+                else:
+                    dist.all_to_all_single(recv, send)
+                torch.cuda.synchronize(stage.device)
+                return 0
+            except Exception:                                         # never raise through the C frame
+                return 1
+        return _lib.ALLTOALL_FN(cb)
 
     def __call__(self, x_local, flags: int = 0):
         """x_local: torch int64 [N/W, 4] on this rank's GPU (Fr Montgomery limbs).  Returns the rank's
         block of the transform in natural order (a new tensor)."""
         import torch
-        inverse, coset = bool(flags & _lib.NTT_INVERSE), bool(flags & _lib.NTT_COSET)
-        ctx, W = self.ctx, self.world
-        n1, n2 = self.n1, self.n2
-        x = x_local.contiguous().clone()
-        if x.shape[0] * W != n1 * n2:
+        W = self.world
+        if x_local.shape[0] * W != self.n1 * self.n2:
             raise Error(_lib.PM_ERR_LENGTH, "x_local must hold N / world elements")
-        # torch's copies / transposes run on torch's stream, the library's kernels on the context's:
-        # order the hand-overs explicitly (torch -> library: synchronize torch; library -> torch: ctx.sync)
+        x = x_local.contiguous().clone()
+        blk = x.shape[0]
+        if self._stage is None or self._stage.device != x.device:
+            self._stage = torch.empty((2 * blk if W > 1 else blk, 4), dtype=torch.int64, device=x.device)
+            self._cb = None if (W == 1 or self.native_comm) else self._exchange_callback(self._stage)
+        # torch's copy runs on torch's stream, the library's kernels on the context's
         torch.cuda.synchronize(x.device)
-        if coset and not inverse:
-            x = self._coset(x, False)
-        sub = _lib.NTT_INVERSE if inverse else 0
-        a = _transpose_exchange(x.view(n1 // W, n2, 4), n1, n2, W)            # [N2/W][N1]: columns, i contiguous
-        torch.cuda.synchronize(x.device)
-        ctx.fr_ntt_dev(a.data_ptr(), n1, a.data_ptr(), self.l1, sub, batch=n2 // W)
-        tw = self._twiddles(inverse, a)
-        cnt = a.shape[0] * n1
-        ctx.fr_vec_op(2, a.data_ptr(), tw.data_ptr(), cnt, a.data_ptr(), cnt)
-        ctx.sync()
-        b = _transpose_exchange(a, n2, n1, W)                                 # [N1/W][N2]: rows k1, j contiguous
-        torch.cuda.synchronize(x.device)
-        ctx.fr_ntt_dev(b.data_ptr(), n2, b.data_ptr(), self.l2, sub, batch=n1 // W)
-        ctx.sync()
-        out = _transpose_exchange(b, n1, n2, W).view(-1, 4)                   # [N2/W][N1] = natural order block
-        torch.cuda.synchronize(x.device)
-        if coset and inverse:
-            out = self._coset(out, True)
-        return out
+        self.ctx.fr_ntt_fourstep_dev(x.data_ptr(), self._stage.data_ptr(), self.log_n, W, self.rank, flags, self._cb)
+        self.ctx.sync()
+        return x

@@ -154,6 +154,14 @@ class Context:
             C.c_void_p(d_out), out_stride if out_stride is not None else n, log_n, batch, flags,
             C.c_void_p(stream)))
 
+    def fr_ntt_fourstep_dev(self, d_inout: int, d_stage: int, log_n: int, world: int, rank: int, flags: int = 0,
+                            exchange=None):
+        """``pm_fr_ntt_fourstep_dev``: this rank's N / world block of a 2^log_n-point transform, in place;
+        ``exchange`` = an ``_lib.ALLTOALL_FN`` or None (the context's RCCL communicator)."""
+        cb = exchange if exchange is not None else C.cast(None, _lib.ALLTOALL_FN)
+        self._check(self._lib.pm_fr_ntt_fourstep_dev(self._h, C.c_void_p(d_inout), C.c_void_p(d_stage), log_n, world,
+                                                     rank, flags, C.cast(cb, C.c_void_p), None))
+
     # ---- device-pointer forms of the polynomial helpers (ints; used by prover.py) -------
     def fr_powers(self, base, scale, n: int, d_out: int):
         """out[i] = scale * base^i."""

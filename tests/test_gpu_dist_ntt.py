@@ -53,22 +53,25 @@ def _worker(rank, world, port, log_ns, q):
         dist.destroy_process_group()
 
 
-def test_four_step_ntt_world2():
+@pytest.mark.parametrize("world,log_ns", [(2, (4, 9, 14)), (4, (4, 7, 11, 13))])
+def test_four_step_ntt_over_ranks(world, log_ns):
+    """`world` ranks on the one GPU of the test box, the all-to-all through the callback (gloo); four ranks
+    exercise the per-peer block indexing of the pack / unpack kernels that two ranks cannot tell apart."""
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, 2, port, (4, 9, 14), q)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, log_ns, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
-@pytest.mark.parametrize("log_n", [2, 7, 12, 16])
+@pytest.mark.parametrize("log_n", [2, 3, 5, 7, 12, 16])
 def test_four_step_ntt_single_rank(ctx, oracle, log_n):
     import torch
     from plonk_prototype_amd.dist import FourStepNTT
@@ -82,6 +85,34 @@ def test_four_step_ntt_single_rank(ctx, oracle, log_n):
     # forward then inverse is the identity
     back = plan(plan(x, 2), 3)
     assert torch.equal(back, x)
+
+
+def test_four_step_ntt_2_20_equals_the_library_plan(ctx, oracle):
+    """Full size on one rank against pm_fr_ntt_dev (the oracle would take too long here): bit for bit, all flags."""
+    import torch
+    from plonk_prototype_amd.dist import FourStepNTT
+    log_n = 20
+    n = 1 << log_n
+    x = torch.from_numpy(oracle.fr_sample(5, n).view(np.int64).copy()).cuda()
+    ref = torch.empty_like(x)
+    plan = FourStepNTT(ctx, log_n)
+    for flags in (0, 1, 2, 3):
+        ctx.fr_ntt_dev(x.data_ptr(), n, ref.data_ptr(), log_n, flags)
+        ctx.sync()
+        assert torch.equal(plan(x, flags), ref), flags
+
+
+def test_four_step_native_entry_point_checks_its_arguments(ctx):
+    import torch
+    import plonk_prototype_amd as pa
+    x = torch.zeros((256, 4), dtype=torch.int64, device="cuda")
+    st = torch.zeros((512, 4), dtype=torch.int64, device="cuda")
+    for world, rank, log_n, flags in ((3, 0, 8, 0), (2, 2, 8, 0), (32, 0, 8, 0), (1, 0, 1, 0), (1, 0, 27, 0), (1, 0, 8, 4)):
+        with pytest.raises(pa.Error):
+            ctx.fr_ntt_fourstep_dev(x.data_ptr(), st.data_ptr(), log_n, world, rank, flags)
+    with pytest.raises(pa.Error) as e:                      # two ranks, no callback, no communicator
+        ctx.fr_ntt_fourstep_dev(x.data_ptr(), st.data_ptr(), 9, 2, 0, 0)
+    assert e.value.code == -7
 
 
 def test_four_step_rejects_bad_shapes(ctx):

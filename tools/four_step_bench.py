@@ -45,3 +45,15 @@ if rank == 0:
         ctx.sync()
         d1 = (time.perf_counter() - t0) / reps
         print(f"library plan 2^{log_n}: {d1 * 1e3:.3f} ms; equal: {torch.equal(out, y)}")
+        # the native entry point alone (no clone of the input, no torch synchronisation), per kernel
+        stage = torch.empty_like(x)
+        w = x.clone()
+        ctx.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.fr_ntt_fourstep_dev(w.data_ptr(), stage.data_ptr(), log_n, 1, 0, 0)
+        ctx.sync()
+        d2 = (time.perf_counter() - t0) / reps
+        prof = ctx.profile_read(); ctx.profile(False)
+        print(f"pm_fr_ntt_fourstep_dev 2^{log_n}: {d2 * 1e3:.3f} ms  kernels_us=" +
+              str({k: round(v[1] / v[0] * 1e3, 1) for k, v in prof.items()}))
