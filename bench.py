@@ -240,7 +240,25 @@ def main():
                                 "all_kernels_us": {s_: round(v[1] / v[0] * 1e3, 2) for s_, v in bprof.items()},
                                 "whole_transform_frac": round(2 * 64 * nb / tb / HBM_PEAK, 4),
                                 "note": "every kernel timed (an event pair costs ~5 us per launch: <1 % at this size)"}}
-            del xb, yb, zb
+            # (iv) SURVEY 8f N5 on one rank: the rank-split transform's own kernels (pack / unpack transposes + the
+            # batched sub-transforms; the all-to-all degenerates to nothing), result equal to the plan's bit for bit
+            ctx.fr_ntt_dev(xb.data_ptr(), nb, yb.data_ptr(), kb, 0, stream=stream)
+            zb.copy_(xb)
+            local_sync()
+            ctx.fr_ntt_fourstep_dev(zb.data_ptr(), yb.data_ptr(), kb, 1, 0, 0)      # yb doubles as the staging buffer
+            ctx.sync()
+            ctx.fr_ntt_dev(xb.data_ptr(), nb, yb.data_ptr(), kb, 0, stream=stream)
+            local_sync()
+            four_ok = bool(torch.equal(zb, yb))
+            stage = torch.empty_like(xb)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.fr_ntt_fourstep_dev(zb.data_ptr(), stage.data_ptr(), kb, 1, 0, 0)
+            ctx.sync()
+            big["fourstep_world1"] = {"ms_per_transform": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                                      "equals_single_gpu_plan": four_ok,
+                                      "note": "pm_fr_ntt_fourstep_dev with world = 1: three pack + unpack transposes and four sub-transform passes; over several GPUs each transpose adds one all-to-all (not measurable on one GPU)"}
+            del xb, yb, zb, stage
         ntt_extra = {"fwd_inv_2^24": big, "pcie_inclusive": {"ms_per_transform": round(e2e * 1e3, 3), "butterflies_per_s": (n // 2) * k / e2e,
                                         "note": "pm_fr_ntt with pageable host buffers: H2D + transform + D2H; never `value`",
                                         "batch4_ms_per_transform": round(pipe[1] * 1e3, 3),
