@@ -49,6 +49,9 @@ def main():
                     help="skip the PCIe-inclusive and coset-4n NTT measurements (PMC passes: one NTT size only)")
     ap.add_argument("--prover-log-n", type=int, default=20,
                     help="gates of the synthetic circuit for the full-prove entry (BASELINE configs[3])")
+    ap.add_argument("--fourstep-log-n", type=int, default=0,
+                    help="N > 1 only, off by default: also time ONE 2^K transform split over the ranks "
+                         "(pm_fr_ntt_fourstep_dev, SURVEY 8f N5) through the library's RCCL communicator")
     args = ap.parse_args()
 
     import torch
@@ -388,6 +391,28 @@ def main():
         if args.msm_large_log_n > args.msm_log_n:
             msm_large, _, _ = run_msm(args.msm_large_log_n, 2, True)
 
+    # ------------------------------------------------------------------ optional: one transform over all ranks (N5)
+    fourstep = None
+    if world > 1 and args.fourstep_log_n and native_comm:
+        fk = args.fourstep_log_n
+        fblk = (1 << fk) // world
+        fx = torch.from_numpy(oracle.fr_sample(0x4E35 + rank, fblk).view(np.int64)).to(dev)
+        fstage = torch.empty((2 * fblk, 4), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        for _ in range(2):
+            ctx.fr_ntt_fourstep_dev(fx.data_ptr(), fstage.data_ptr(), fk, world, rank, 0)
+        ctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ctx.fr_ntt_fourstep_dev(fx.data_ptr(), fstage.data_ptr(), fk, world, rank, 0)
+        ctx.sync()
+        barrier()
+        fdt = max_over_ranks(time.perf_counter() - t0) / 10
+        fourstep = {"log_n": fk, "ms_per_transform": round(fdt * 1e3, 3), "butterflies_per_s": (1 << (fk - 1)) * fk / fdt,
+                    "scaling": "strong", "exchange": "grouped ncclSend / ncclRecv inside the library, three all-to-alls per transform"}
+        del fx, fstage
+
     # ------------------------------------------------------------------ next rows (N1/N2 helpers), rank 0
     poly = None
     if rank == 0 and not args.no_poly:
@@ -641,7 +666,7 @@ def main():
                           "parallelism": f"{world} independent polynomial(s), one per GPU"},
                "exchange": (None if world == 1 else "library RCCL communicator (pm_comm_init / pm_g1_allgather_fold)"
                             if native_comm else f"torch.distributed ({backend})"),
-               "roofline": roofline, "cpu_baseline": cpu, "ntt_extra": ntt_extra, "msm": msm, "msm_large": msm_large, "next_rows": poly,
+               "roofline": roofline, "cpu_baseline": cpu, "ntt_extra": ntt_extra, "ntt_fourstep": fourstep, "msm": msm, "msm_large": msm_large, "next_rows": poly,
                "prover": prover}
         print(json.dumps(out))
     ctx.close()
