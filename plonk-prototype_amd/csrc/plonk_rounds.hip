@@ -126,22 +126,36 @@ struct WidgetConsts {
   u32 var_sep[9], var_k[2][9];
 };
 
-// Widget arithmetic: every value in device form with normalised limbs and value < 1.02 r, closed
+// Widget arithmetic: every value in device form with normalised limbs and value < 1.05 r, closed
 // under these three (fe_mul: < x y / 2^261 + r; the weak reduction after + and - brings the value
 // back below r + r / 2^16).  Slower than the hand-scheduled lazy sums of the arithmetic identity, but
 // the widget rows are a small part of real circuits and the kernel stays VALU-bound either way.
 PM_DEV Fr wadd(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_add<FrP>(a, b)); }
 PM_DEV Fr wsub(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_sub<FrP, 2, 1>(a, b)); }
 PM_DEV Fr wmul(const Fr& a, const Fr& b) { return fe_mul<FrP>(a, b); }
+// a - b + 2r left unreduced (limbs < 2^31, value < 3.02 r): only as the FIRST operand of a product whose second
+// operand is closed (fe_mul: first-operand limbs < 6 * 2^29, value bounds 3.02 x 1.02 << 68)
+PM_DEV Fr wsub_lazy(const Fr& a, const Fr& b) { return fe_sub<FrP, 2, 1>(a, b); }
+// small multiples by additions (a product is ~225 instructions, an addition 9, a weak reduction ~40)
+PM_DEV Fr wmul2(const Fr& a) { return fe_reduce_weak<FrP>(fe_add<FrP>(a, a)); }
+PM_DEV Fr wmul3(const Fr& a) { return fe_reduce_weak<FrP>(fe_add<FrP>(fe_add<FrP>(a, a), a)); }
+PM_DEV Fr wmul4(const Fr& a) {
+  const Fr t = fe_add<FrP>(a, a);                        // limbs < 2^30 + ., value < 2.04 r
+  return fe_reduce_weak<FrP>(fe_add<FrP>(t, t));         // limbs < 2^31 + ., value < 4.08 r
+}
+PM_DEV Fr wmul9(const Fr& a) {
+  const Fr f = wmul4(a);
+  return fe_reduce_weak<FrP>(fe_add<FrP>(fe_add<FrP>(f, f), a));   // 2 (4a) + a
+}
 // f (f - 1)(f - 2)(f - 3): zero exactly on the quads 0..3
 PM_DEV Fr wdelta(const Fr& f, const WidgetConsts& c) {
-  Fr r = wmul(f, wsub(f, fr_limbs(c.c1)));
-  r = wmul(r, wsub(f, fr_limbs(c.c2)));
-  return wmul(r, wsub(f, fr_limbs(c.c3)));
+  Fr r = wmul(wsub_lazy(f, fr_limbs(c.c1)), f);
+  r = wmul(wsub_lazy(f, fr_limbs(c.c2)), r);
+  return wmul(wsub_lazy(f, fr_limbs(c.c3)), r);
 }
 
 template <bool WIDGETS>
-__global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const RoundConsts kc, const WidgetConsts wc,
+__global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, const RoundConsts kc, const WidgetConsts wc,
                                                        size_t n4) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;   // a multiple of 4: i mod 4 is fixed per thread
   const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,18 +183,17 @@ __global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const R
       const Fr a = w[0], b = w[1], c = w[2], d = w[3];
       const Fr an = to_dev(ld_canon(p.w[0], inext)), bn = to_dev(ld_canon(p.w[1], inext)),
                dn = to_dev(ld_canon(p.w[3], inext));
-      const Fr c4 = fr_limbs(wc.c4);
       Fr wsum = fe_zero<FrP>();
       if (p.q_range) {
-        Fr t = wdelta(wsub(c, wmul(d, c4)), wc);
-        t = wadd(t, wmul(wdelta(wsub(b, wmul(c, c4)), wc), fr_limbs(wc.range_k[0])));
-        t = wadd(t, wmul(wdelta(wsub(a, wmul(b, c4)), wc), fr_limbs(wc.range_k[1])));
-        t = wadd(t, wmul(wdelta(wsub(dn, wmul(a, c4)), wc), fr_limbs(wc.range_k[2])));
+        Fr t = wdelta(wsub(c, wmul4(d)), wc);
+        t = wadd(t, wmul(wdelta(wsub(b, wmul4(c)), wc), fr_limbs(wc.range_k[0])));
+        t = wadd(t, wmul(wdelta(wsub(a, wmul4(b)), wc), fr_limbs(wc.range_k[1])));
+        t = wadd(t, wmul(wdelta(wsub(dn, wmul4(a)), wc), fr_limbs(wc.range_k[2])));
         t = wmul(t, fr_limbs(wc.range_sep));
         wsum = wadd(wsum, wmul(to_dev(ld_canon(p.q_range, i)), t));
       }
       if (p.q_logic) {
-        const Fr qa = wsub(an, wmul(a, c4)), qb = wsub(bn, wmul(b, c4)), qd = wsub(dn, wmul(d, c4));
+        const Fr qa = wsub(an, wmul4(a)), qb = wsub(bn, wmul4(b)), qd = wsub(dn, wmul4(d));
         const Fr qc = to_dev(ld_canon(p.q_c, i));
         Fr t = wdelta(qa, wc);
         t = wadd(t, wmul(wdelta(qb, wc), fr_limbs(wc.logic_k[0])));
@@ -188,12 +201,12 @@ __global__ void __launch_bounds__(256) quotient_kernel(const QuotPtrs p, const R
         t = wadd(t, wmul(wsub(c, wmul(qa, qb)), fr_limbs(wc.logic_k[2])));
         // delta_xor_and(qa, qb, w = c, qd, q_c)
         const Fr s = wadd(qa, qb);
-        Fr in = wadd(wsub(wmul(c, c4), wmul(s, fr_limbs(wc.c18))), fr_limbs(wc.c81));            // 4w - 18(a+b) + 81
+        Fr in = wadd(wsub(wmul4(c), wmul2(wmul9(s))), fr_limbs(wc.c81));                         // 4w - 18(a+b) + 81
         in = wadd(wmul(c, in), wmul(wadd(wmul(qa, qa), wmul(qb, qb)), fr_limbs(wc.c18)));        // w(..) + 18(a^2+b^2)
         in = wadd(wsub(in, wmul(s, fr_limbs(wc.c81))), fr_limbs(wc.c83));                        // - 81(a+b) + 83
         const Fr ff = wmul(c, in);
-        const Fr e = wsub(wmul(wadd(s, qd), fr_limbs(wc.c3)), wadd(ff, ff));                    // 3(a+b+c) - 2f
-        const Fr bb = wmul(qc, wsub(wmul(qd, fr_limbs(wc.c9)), wmul(s, fr_limbs(wc.c3))));      // q_c (9c - 3(a+b))
+        const Fr e = wsub(wmul3(wadd(s, qd)), wadd(ff, ff));                                    // 3(a+b+c) - 2f
+        const Fr bb = wmul(qc, wsub(wmul9(qd), wmul3(s)));                                      // q_c (9c - 3(a+b))
         t = wadd(t, wmul(wadd(bb, e), fr_limbs(wc.logic_k[3])));
         t = wmul(t, fr_limbs(wc.logic_sep));
         wsum = wadd(wsum, wmul(to_dev(ld_canon(p.q_logic, i)), t));
