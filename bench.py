@@ -598,6 +598,32 @@ def main():
                   "kzg_opening_equation_holds": kzg_ok, "srs_setup_ms": round(srs_ms, 1) if srs_ms else None,
                   "inputs": "witness resident in HBM; proving key, verifier key and SRS table resident"}
         d_wit.free()
+        if world == 1:
+            # every gate kind: the same size with all 11 selector polynomials present (wide_mixed_circuit: half the
+            # rows arithmetic, blocks of rows under each widget selector), i.e. the quotient and linearisation of a
+            # real dusk-plonk circuit -- the arithmetic-only circuit above skips the widget arithmetic
+            pkey.free()
+            m_circ, m_wit, _ = pa.synthetic.wide_mixed_circuit(gn, ctx, 3)
+            m_key = pa.preprocess(m_circ, ctx, ck)
+            del m_circ
+            m_proof = pa.prove(m_key, ck, m_wit, None)
+            m_times = []
+            for _ in range(5):
+                ctx.sync()
+                t0 = time.perf_counter()
+                pa.prove(m_key, ck, m_wit, None)
+                m_times.append(time.perf_counter() - t0)
+            ctx.profile(True)
+            pa.prove(m_key, ck, m_wit, None)
+            mprof = ctx.profile_read()
+            ctx.profile(False)
+            prover["all_gate_kinds"] = {
+                "workload": f"2^{gk} gates, all 11 selector polynomials present (arithmetic, range, logic, fixed-base and variable-base rows)",
+                "ms_per_proof": round(float(np.median(m_times)) * 1e3, 2),
+                "quotient_ms": round(mprof["plonk_quotient"][1] / mprof["plonk_quotient"][0], 3),
+                "verifier_identity_holds": bool(pa.prover.check_identity(m_proof, gn, 0))}
+            m_wit.free()
+            m_key.free()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # the same rounds on the host cores: the C restatement composed by oracle/cpu_prover.py, on a
             # bounded sample (a 2^16-gate circuit), outputs compared with a GPU proof of that circuit

@@ -249,3 +249,41 @@ def wide_circuit(n: int, ctx: Context, seed: int = 1):
                       q_4=q["q_4"], q_c=q["q_c"], q_arith=np.tile(fr_to_limbs(1), (n, 1)),
                       sigma_index=sigma.reshape(4, n))
     return circuit, wit, None
+
+
+def wide_mixed_circuit(n: int, ctx: Context, seed: int = 1):
+    """wide_circuit on the lower half of the rows; the upper half holds zero rows (every wire 0, copy permutation the
+    identity there) on which each of the four widget selectors is switched on over its own block -- zero rows
+    satisfy the range, logic, fixed-base and variable-base identities (every quad, bit and product is 0), so the
+    circuit is valid and a proof of it runs the full widget arithmetic of the quotient and linearisation at 4n
+    resp. n points: the cost of a real dusk-plonk circuit's gate mix at a size no per-gate generator reaches in
+    seconds.  The last rows of every block stay plain (the widgets read the NEXT row's wires).
+    -> (Circuit, witness DeviceVector [a | b | c | d], None)."""
+    if n < 64 or n & (n - 1):
+        raise ValueError("n must be a power of two >= 64")
+    h = n // 2
+    base, wit_h, _ = wide_circuit(h, ctx, seed)
+    zero = np.zeros((h, 4), np.uint64)
+    up = lambda a: np.concatenate([a, zero])                           # noqa: E731
+    one = fr_to_limbs(1)
+    blk = h // 4
+
+    def block_selector(k):
+        q = np.zeros((n, 4), np.uint64)
+        q[h + k * blk: h + (k + 1) * blk - 2] = one
+        return q
+
+    sig = np.empty((4, n), np.int64)
+    for j in range(4):
+        lo = base.sigma_index[j]
+        sig[j, :h] = (lo // h) * n + (lo % h)                          # j' h + i' -> j' n + i'
+        sig[j, h:] = j * n + np.arange(h, n)
+    q_arith = np.concatenate([base.q_arith, zero])
+    circuit = Circuit(q_m=up(base.q_m), q_l=up(base.q_l), q_r=up(base.q_r), q_o=up(base.q_o), q_4=up(base.q_4), q_c=up(base.q_c),
+                      q_arith=q_arith, q_range=block_selector(0), q_logic=block_selector(1),
+                      q_fixed_group_add=block_selector(2), q_variable_group_add=block_selector(3), sigma_index=sig)
+    w = wit_h.to_host().reshape(4, h, 4)
+    wit_h.free()
+    full = np.zeros((4, n, 4), np.uint64)
+    full[:, :h] = w
+    return circuit, DeviceVector.from_host(ctx, full.reshape(4 * n, 4)), None

@@ -1,6 +1,8 @@
 """Wall time and per-kernel time of prove() on a synthetic chain circuit.
-usage: python tools/prover_bench.py LOG_N [REPS] [wide]
-"wide" uses synthetic.wide_circuit (generated with the GPU's help in seconds; for 2^22 and up)."""
+usage: python tools/prover_bench.py LOG_N [REPS] [wide|mixed]
+"wide" uses synthetic.wide_circuit (generated with the GPU's help in seconds; for 2^22 and up), "mixed"
+synthetic.wide_mixed_circuit (the same on half of the rows plus blocks of rows under each widget selector: all 11
+selector polynomials present, the quotient / linearisation run the full widget arithmetic).""" 
 import os
 import sys
 import time
@@ -16,10 +18,11 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = 1 << log_n
 orc = CpuOracle()
 t0 = time.time()
-wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+wide = mode in ("wide", "mixed")
 ctx = pa.Context(0)
 if wide:
-    circuit, dw, _ = pa.synthetic.wide_circuit(n, ctx, 1)
+    circuit, dw, _ = (pa.synthetic.wide_mixed_circuit if mode == "mixed" else pa.synthetic.wide_circuit)(n, ctx, 1)
     pi = np.zeros((n, 4), np.uint64)
 else:
     circuit, wit, pi = pa.synthetic.chain_circuit(n, 1)
