@@ -133,9 +133,6 @@ struct WidgetConsts {
 PM_DEV Fr wadd(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_add<FrP>(a, b)); }
 PM_DEV Fr wsub(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_sub<FrP, 2, 1>(a, b)); }
 PM_DEV Fr wmul(const Fr& a, const Fr& b) { return fe_mul<FrP>(a, b); }
-// a - b + 2r left unreduced (limbs < 2^31, value < 3.02 r): only as the FIRST operand of a product whose second
-// operand is closed (fe_mul: first-operand limbs < 6 * 2^29, value bounds 3.02 x 1.02 << 68)
-PM_DEV Fr wsub_lazy(const Fr& a, const Fr& b) { return fe_sub<FrP, 2, 1>(a, b); }
 // small multiples by additions (a product is ~225 instructions, an addition 9, a weak reduction ~40)
 PM_DEV Fr wmul2(const Fr& a) { return fe_reduce_weak<FrP>(fe_add<FrP>(a, a)); }
 PM_DEV Fr wmul3(const Fr& a) { return fe_reduce_weak<FrP>(fe_add<FrP>(fe_add<FrP>(a, a), a)); }
@@ -147,11 +144,12 @@ PM_DEV Fr wmul9(const Fr& a) {
   const Fr f = wmul4(a);
   return fe_reduce_weak<FrP>(fe_add<FrP>(fe_add<FrP>(f, f), a));   // 2 (4a) + a
 }
-// f (f - 1)(f - 2)(f - 3): zero exactly on the quads 0..3
+PM_DEV Fr wsqr(const Fr& a) { return fe_sqr<FrP>(a); }
+// f (f - 1)(f - 2)(f - 3) = u (u + 2) with u = f^2 - 3 f: zero exactly on the quads 0..3; one squaring and one
+// product instead of three products
 PM_DEV Fr wdelta(const Fr& f, const WidgetConsts& c) {
-  Fr r = wmul(wsub_lazy(f, fr_limbs(c.c1)), f);
-  r = wmul(wsub_lazy(f, fr_limbs(c.c2)), r);
-  return wmul(wsub_lazy(f, fr_limbs(c.c3)), r);
+  const Fr u = wsub(wsqr(f), wmul3(f));
+  return wmul(fe_add<FrP>(u, fr_limbs(c.c2)), u);          // first operand unreduced: limbs < 2^30 + ., value < 2.02 r
 }
 
 template <bool WIDGETS>
@@ -202,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
         // delta_xor_and(qa, qb, w = c, qd, q_c)
         const Fr s = wadd(qa, qb);
         Fr in = wadd(wsub(wmul4(c), wmul2(wmul9(s))), fr_limbs(wc.c81));                         // 4w - 18(a+b) + 81
-        in = wadd(wmul(c, in), wmul(wadd(wmul(qa, qa), wmul(qb, qb)), fr_limbs(wc.c18)));        // w(..) + 18(a^2+b^2)
+        in = wadd(wmul(c, in), wmul2(wmul9(wadd(wsqr(qa), wsqr(qb)))));                          // w(..) + 18(a^2+b^2)
         in = wadd(wsub(in, wmul(s, fr_limbs(wc.c81))), fr_limbs(wc.c83));                        // - 81(a+b) + 83
         const Fr ff = wmul(c, in);
         const Fr e = wsub(wmul3(wadd(s, qd)), wadd(ff, ff));                                    // 3(a+b+c) - 2f
@@ -216,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
         const Fr one = fr_limbs(wc.c1);
         const Fr bit = wsub(dn, wadd(d, d));
         Fr t = wmul(wmul(bit, wsub(bit, one)), wadd(bit, one));                                 // bit (bit-1)(bit+1)
-        const Fr ya = wadd(wmul(wmul(bit, bit), wsub(yb, one)), one);
+        const Fr ya = wadd(wmul(wsqr(bit), wsub(yb, one)), one);
         const Fr xa = wmul(xb, bit);
         t = wadd(t, wmul(wsub(wmul(bit, xyb), c), fr_limbs(wc.fixed_k[0])));
         const Fr dxy = wmul(wmul(wmul(c, a), b), fr_limbs(wc.edwards_d));
