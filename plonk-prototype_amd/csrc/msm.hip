@@ -197,6 +197,13 @@ __global__ void msm_digits_kernel(const u32x4* scalars, size_t n, size_t sc_stri
   }
 }
 
+// buckets[b].ZZ <- 0 (four 16-byte stores per bucket, one per thread): the identity, see ld_xyzz
+__global__ void msm_clear_buckets_kernel(u32x4* buckets, size_t nb) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb * 4) return;
+  buckets[16 * (t >> 2) + 8 + (t & 3)] = u32x4{0u, 0u, 0u, 0u};
+}
+
 // ------------------------------------------------------------------ 3: segmented accumulate
 struct AccArgs {
   const u32* keys;
@@ -757,7 +764,10 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     PM_HIP(ctx, sort_pairs(ws + o_sort, sort_tmp, keys0, keys1, vals0, vals1, m, g.key_bits, st));
   }
   // 3 accumulate
-  PM_HIP(ctx, hipMemsetAsync(buckets, 0, total_buckets * 256, st));
+  // empty buckets = the identity = ZZ all zero: only that quarter of every 256-byte record is cleared
+  hipLaunchKernelGGL(msm_clear_buckets_kernel, dim3((unsigned)((total_buckets * 4 + 255) / 256)), dim3(256), 0, st, buckets,
+                     total_buckets);
+  PM_HIP(ctx, hipGetLastError());
   AccArgs a;
   memset(&a, 0, sizeof a);
   a.bases = (const u32x4*)(bases->table_c ? bases->d_table : bases->d_xy);
