@@ -175,6 +175,8 @@ int pm_g1_fold(const uint64_t* xyz_parts, size_t k, uint64_t out_xyz[18]);
 
 /* Projective (homogeneous X/Z, Y/Z) -> affine; *is_identity = 1 and xy = 0 for infinity. */
 int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_identity);
+/* k points ([k][18] -> [k][12], is_identity[k] optional) with one field inversion. */
+int pm_g1_to_affine_batch(const uint64_t* xyz, size_t k, uint64_t* xy, int* is_identity);
 
 /* ---- device-resident polynomial helpers (the callers either side of the hot path) ------- */
 /* dusk_plonk::fft::{Polynomial, Evaluations} and

@@ -75,6 +75,7 @@ SIGNATURES = {
                                       C.c_uint32, C.c_uint32, u64p, C.c_void_p]),
     "pm_g1_fold": (C.c_int, [u64p, C.c_size_t, u64p]),
     "pm_g1_to_affine": (C.c_int, [u64p, u64p, C.POINTER(C.c_int)]),
+    "pm_g1_to_affine_batch": (C.c_int, [u64p, C.c_size_t, u64p, C.POINTER(C.c_int)]),
     "pm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pm_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -1073,6 +1073,36 @@ extern "C" int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_
   return PM_OK;
 }
 
+// k points at once with ONE field inversion (Montgomery's trick over the Z coordinates; identities are skipped and
+// come back as (0, 0)): what a prover round's batch of commitments needs -- a host inversion is ~50 us.
+extern "C" int pm_g1_to_affine_batch(const uint64_t* xyz, size_t k, uint64_t* xy, int* is_identity) {
+  if ((!xyz || !xy) && k) return PM_ERR_BAD_ARG;
+  const host::Field<6>& F = host::FP();
+  std::vector<HFp> Z(k), pre(k);
+  HFp acc = host::one(F);
+  for (size_t i = 0; i < k; ++i) {
+    memcpy(Z[i].l, xyz + 18 * i + 12, 48);
+    pre[i] = acc;                                   // product of the earlier non-zero Z
+    if (!host::is_zero(Z[i])) acc = host::mul(acc, Z[i], F);
+  }
+  HFp inv = host::inv(acc, F);
+  memset(xy, 0, 96 * k);
+  for (size_t i = k; i-- > 0;) {
+    const bool ident = host::is_zero(Z[i]);
+    if (is_identity) is_identity[i] = ident ? 1 : 0;
+    if (ident) continue;
+    const HFp zi = host::mul(inv, pre[i], F);       // 1 / Z_i
+    inv = host::mul(inv, Z[i], F);
+    HFp X, Y;
+    memcpy(X.l, xyz + 18 * i, 48);
+    memcpy(Y.l, xyz + 18 * i + 6, 48);
+    const HFp x = host::mul(X, zi, F), y = host::mul(Y, zi, F);
+    memcpy(xy + 12 * i, x.l, 48);
+    memcpy(xy + 12 * i + 6, y.l, 48);
+  }
+  return PM_OK;
+}
+
 // Device-resident affine points (ABI layout) -> pm_bases, no host round trip (an SRS generated or
 // received on the GPU).
 extern "C" int pm_g1_bases_from_dev(pm_ctx* ctx, const void* d_xy, size_t n, pm_bases** out) {

@@ -426,11 +426,7 @@ static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const 
     if (rc == PM_OK && xrc != PM_OK) rc = xrc;
   }
   if (rc) return rc;
-  for (uint32_t b = 0; b < batch; ++b) {
-    int ident = 0;
-    PK_TRY(pm_g1_to_affine(xyz + 18 * b, out_xy[b], &ident));
-  }
-  return PM_OK;
+  return pm_g1_to_affine_batch(xyz, batch, &out_xy[0][0], nullptr);   // one host inversion per batch
 }
 
 static int key_commit_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard,

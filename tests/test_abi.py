@@ -158,3 +158,41 @@ def test_exchange_fold_of_gathered_messages():
     bad[2, 0] = 3                                                      # ranks out of step
     assert lib.pm_test_fold_gathered(bad.ctypes.data_as(u64p), world, k, out.ctypes.data_as(u64p)) == _lib.PM_ERR_EXCHANGE
     assert lib.pm_test_fold_gathered(msgs.ctypes.data_as(u64p), world, 17, out.ctypes.data_as(u64p)) == _lib.PM_ERR_BAD_ARG
+
+
+def test_affine_conversion_of_a_batch():
+    """pm_g1_to_affine_batch (one inversion for k points, host code) == pm_g1_to_affine point by point, with
+    identities in the batch and Z != 1 (a folded point)."""
+    import ctypes as C
+    import plonk_prototype_amd as pa
+    from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+    lib = pa.load()
+    o = CpuOracle()
+    G = o.g1_generator()
+    one = o.fp_to_mont(ints_to_limbs([1], 6))[0]
+    u64p = C.POINTER(C.c_uint64)
+
+    def proj(k):
+        p = np.zeros(18, np.uint64)
+        if k:
+            p[:12] = o.g1_mul(G, ints_to_limbs([k], 4)[0])
+            p[12:] = one
+        else:
+            p[6:12] = one
+        return p
+    # pm_g1_fold of two points leaves a projective point with Z != 1
+    parts = np.stack([proj(3), proj(9)])
+    folded = np.zeros(18, np.uint64)
+    assert lib.pm_g1_fold(parts.ctypes.data_as(u64p), 2, folded.ctypes.data_as(u64p)) == 0
+    pts = np.stack([proj(5), proj(0), folded, proj(123456789), proj(0)])
+    k = pts.shape[0]
+    got = np.zeros((k, 12), np.uint64)
+    ident = (C.c_int * k)()
+    assert lib.pm_g1_to_affine_batch(pts.ctypes.data_as(u64p), k, got.ctypes.data_as(u64p), ident) == 0
+    for i in range(k):
+        exp = np.zeros(12, np.uint64)
+        one_ident = C.c_int(0)
+        assert lib.pm_g1_to_affine(pts[i].ctypes.data_as(u64p), exp.ctypes.data_as(u64p), C.byref(one_ident)) == 0
+        assert np.array_equal(got[i], exp) and ident[i] == one_ident.value, i
+    assert np.array_equal(got[2], o.g1_mul(G, ints_to_limbs([12], 4)[0])) and list(ident) == [0, 1, 0, 0, 1]
+    assert lib.pm_g1_to_affine_batch(None, 0, None, None) == 0
