@@ -598,6 +598,34 @@ static void write_projective(uint64_t out[18], const XYZZ& p) {
   memcpy(out + 6, y.l, 48);
   memcpy(out + 12, host::FP().one, 48);
 }
+// the same for k points with ONE field inversion (Montgomery's trick over the ZZZ coordinates): a host inversion
+// is ~50 us, a prover round's batch has four results
+static void write_projective_batch(uint64_t* out /* k x 18 */, const XYZZ* p, size_t k) {
+  const host::Field<6>& F = host::FP();
+  std::vector<HFp> pre(k);
+  HFp acc = host::one(F);
+  for (size_t i = 0; i < k; ++i) {
+    pre[i] = acc;
+    if (!host::is_zero(p[i].zz)) acc = host::mul(acc, p[i].zzz, F);
+  }
+  HFp inv = host::inv(acc, F);
+  memset(out, 0, k * 18 * 8);
+  for (size_t i = k; i-- > 0;) {
+    uint64_t* o = out + 18 * i;
+    if (host::is_zero(p[i].zz)) {
+      memcpy(o + 6, F.one, 48);  // (0, 1, 0)
+      continue;
+    }
+    const HFp zi = host::mul(inv, pre[i], F);                       // 1 / ZZZ_i
+    inv = host::mul(inv, p[i].zzz, F);
+    const HFp t = host::mul(zi, p[i].zz, F);                        // ZZ / ZZZ
+    const HFp x = host::mul(p[i].x, host::mul(t, t, F), F);         // X / ZZ
+    const HFp y = host::mul(p[i].y, zi, F);
+    memcpy(o, x.l, 48);
+    memcpy(o + 6, y.l, 48);
+    memcpy(o + 12, F.one, 48);
+  }
+}
 static XYZZ projective_to_xyzz(const uint64_t* xyz) {  // homogeneous (X/Z, Y/Z)
   const host::Field<6>& F = host::FP();
   HFp X, Y, Z;
@@ -858,6 +886,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
     return acc;
   };
+  std::vector<XYZZ> totals(batch);
   for (u32 j = 0; j < batch; ++j) {
     XYZZ total = host::xyzz_identity();
     for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no window doublings at all
@@ -865,8 +894,9 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
         for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
       total = host::xyzz_add(total, set_total((size_t)j * g.nsets + w));
     }
-    write_projective(out_xyz + 18 * j, total);
+    totals[j] = total;
   }
+  write_projective_batch(out_xyz, totals.data(), batch);
   return PM_OK;
 }
 
@@ -1085,7 +1115,8 @@ extern "C" int pm_g1_to_affine_batch(const uint64_t* xyz, size_t k, uint64_t* xy
     pre[i] = acc;                                   // product of the earlier non-zero Z
     if (!host::is_zero(Z[i])) acc = host::mul(acc, Z[i], F);
   }
-  HFp inv = host::inv(acc, F);
+  // results of pm_g1_msm* and pm_g1_fold are already normalised (Z = 1): then there is nothing to invert
+  HFp inv = memcmp(acc.l, F.one, 48) == 0 ? acc : host::inv(acc, F);
   memset(xy, 0, 96 * k);
   for (size_t i = k; i-- > 0;) {
     const bool ident = host::is_zero(Z[i]);
