@@ -135,7 +135,7 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
       for (void* t : kv.second.pass_tw) (void)hipFree(t);
     }
   }
-  for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws,
+  for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws, &ctx->msm_ctl,
                           &ctx->msm_scalars, &ctx->poly_ws, &ctx->poly_tab})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);

@@ -54,8 +54,11 @@ struct pm_ctx {
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
   pm::StreamOrder ord_ntt, ord_msm, ord_poly;           // cross-stream ordering of the shared scratch + tables
   std::map<const void*, bool> big_lds_set;              // kernels whose dynamic-LDS limit was already raised
+  std::map<const void*, size_t> big_lds;                // ... and the limit set, where it depends on the call
   // MSM workspaces
   pm::DeviceBuffer msm_ws;
+  pm::DeviceBuffer msm_ctl;                             // control block of the bucket fill (msm_sort.cuh): zero when idle
+  unsigned msm_ctl_cap = 0;                             // partitions it is laid out for
   pm::DeviceBuffer msm_scalars;
   pm::DeviceBuffer poly_ws;                             // scratch of the polynomial helpers
   pm::DeviceBuffer poly_tab;                            // power tables of pm_fr_poly_ruffini_dev

@@ -242,6 +242,41 @@ PM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   t.l[N - 1] = (u32)acc;
   return t;
 }
+// a * b0 / R for a one-limb b0 (< 2^W): the reduction half of fe_mul only (N + N(N-1) limb products instead of
+// 2 N^2 - N).  Same bounds and result class as fe_mul.  Used for Montgomery -> integer: x 2^256 * 2^5 / 2^261.
+template <class P>
+PM_DEV Fe<P> fe_mul_limb(const Fe<P>& a, u32 b0) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q[N];
+  Fe<P> t;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    acc += (u64)a.l[k] * b0;
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (u64)q[i] * M.v[k - i];
+    if (M.v[0] == 1u) {
+      q[k] = (0u - (u32)acc) & MASK;
+      acc += q[k];
+    } else {
+      q[k] = ((u32)acc * NINV) & MASK;
+      acc += (u64)q[k] * M.v[0];
+    }
+    acc >>= W;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) acc += (u64)q[i] * M.v[k - i];
+    t.l[k - N] = (u32)acc & MASK;
+    acc >>= W;
+  }
+  t.l[N - 1] = (u32)acc;
+  return t;
+}
 // a^2 with the cross terms taken once against a pre-doubled copy: N(N+1)/2 products instead of
 // N^2 for the a*a part (the reduction part is unchanged).  Same bounds as fe_mul(a, a).
 template <class P>

@@ -5,11 +5,10 @@
 // by dusk_plonk's CommitKey::commit (ref:Cargo.toml:19).  SURVEY.md CS-4, section 8a a8-a10.
 //
 // Pipeline (all on one stream, no host round trip until the window sums come back):
-//   1 msm_digits      scalar -> canonical integer -> signed c-bit digits; one (key, value)
-//                     pair per (window, point): key = window << (c-1) | (|d| - 1),
-//                     value = point index | sign << 31; zero digits get a trash key
-//   2 radix sort      pairs by key (rocPRIM onesweep over key_bits, digit width chosen here) -> every bucket's
-//                     points are contiguous; the sum is order independent (exact group law)
+//   1 + 2 bucket fill  (msm_sort.cuh) scalar -> canonical integer -> signed c-bit digits; one (key, value) pair per
+//                     non-zero digit: key = window << (c-1) | (|d| - 1), value = point index | sign << 31;
+//                     the pairs grouped by key with a hand-written partition + local counting sort -> every
+//                     bucket's points are contiguous; the sum is order independent (exact group law)
 //   3 msm_accumulate  segmented reduction with a FIXED chunk of sorted entries per thread, so
 //                     load balance does not depend on the scalar distribution (all-equal
 //                     scalars, the 0/1-heavy witness vectors of a real prover): runs inside a
@@ -28,52 +27,19 @@
 // the buckets), a window width chosen for the GPU, sort + segmented sum instead of a serial
 // bucket loop.  The result is the same group element, returned in affine-normalised form.
 #include <hip/hip_runtime.h>
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "context.h"
 #include "ec.cuh"
 #include "host_field.h"
+#include "msm_sort.cuh"
 
 namespace pm {
-
-static constexpr u32 KEY_INVALID = 0xffffffffu;
-
-struct MsmGeom {
-  u32 c;         // window bits
-  u32 nwin;      // digit windows
-  u32 nsets;     // bucket sets per MSM: nwin, or 1 when the bases carry a table of 2^(c w) P
-  u32 batch;     // MSMs sharing the bases in this launch sequence (their sets are laid side by side)
-  u32 bbits;     // c - 1: bits of the bucket field
-  u32 nbuckets;  // 1 << bbits per set
-  u32 key_bits;  // bits of a sort key (set || bucket, plus room for the trash key)
-  u32 trash;     // key of zero digits (sorts last)
-  u32 row_stride;  // table mode: points per table row (value = window * row_stride + index)
-};
-
-static MsmGeom make_geom(size_t n, long opt_c, u32 table_c, size_t table_stride, u32 batch) {
-  MsmGeom g;
-  u32 lg = 0;
-  while (((size_t)1 << (lg + 1)) <= std::max<size_t>(n, 1)) ++lg;
-  long c = opt_c ? opt_c : std::min<long>(16, std::max<long>(5, (long)lg - 4));
-  if (table_c) c = table_c;  // fixed when the table was built
-  g.c = (u32)c;
-  g.nwin = (256 + g.c - 1) / g.c;
-  g.nsets = table_c ? 1u : g.nwin;
-  g.batch = batch;
-  g.bbits = g.c - 1;
-  g.nbuckets = 1u << g.bbits;
-  u32 wb = 0;
-  while ((1u << wb) < g.nsets * batch + 1) ++wb;  // room for set == nsets * batch (trash)
-  g.key_bits = g.bbits + wb;
-  g.trash = (g.nsets * batch) << g.bbits;
-  g.row_stride = (u32)table_stride;
-  return g;
-}
 
 // ------------------------------------------------------------------ bases
 // ABI affine (R = 2^384 Montgomery, canonical) -> device form (R' = 2^392, canonical saturated)
@@ -155,48 +121,6 @@ __global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scr
   }
 }
 
-// ------------------------------------------------------------------ 1: digits
-__global__ void msm_digits_kernel(const u32x4* scalars, size_t n, size_t sc_stride, u32 scalar_form, MsmGeom g,
-                                  u32 offset, u32* keys, u32* vals) {
-  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over batch * n
-  const size_t total = (size_t)g.batch * n;
-  if (gi >= total) return;
-  const u32 j = (u32)(gi / n);          // which MSM of the batch
-  const size_t i = gi - (size_t)j * n;  // which scalar / base
-  Fr s = fe_load<FrP>(scalars + 2 * ((size_t)j * sc_stride + i));
-  // Montgomery (x * 2^256): multiply by 2^5 / 2^261 -> x.   Canonical: multiply by one -> x mod r.
-  Fr f;
-  if (scalar_form == PM_SCALAR_MONTGOMERY) {
-    f = fe_zero<FrP>();
-    f.l[0] = 32u;
-  } else {
-    f = fe_one<FrP>();
-  }
-  u32 w[9];
-  fe_canon_pack<FrP>(w, fe_mul<FrP>(s, f));
-  w[8] = 0;
-  u32 carry = 0;
-  const u32 half = 1u << g.bbits;
-  for (u32 k = 0; k < g.nwin; ++k) {
-    const u32 lo = k * g.c, word = lo >> 5, sh = lo & 31;
-    u64 two = (u64)w[word] | ((u64)(word + 1 < 9 ? w[word + 1] : 0u) << 32);
-    u32 d = (u32)(two >> sh) & ((1u << g.c) - 1u);
-    d += carry;
-    u32 neg = 0;
-    if (d > half) {
-      d = (1u << g.c) - d;
-      neg = 1;
-      carry = 1;
-    } else {
-      carry = 0;
-    }
-    const u32 set = j * g.nsets + (g.nsets == 1 ? 0u : k);
-    keys[(size_t)k * total + gi] = d ? ((set << g.bbits) | (d - 1)) : g.trash;
-    // table of 2^(c k) P (nsets == 1): every window feeds the one bucket set of its MSM
-    vals[(size_t)k * total + gi] = ((g.nsets == 1 ? k * g.row_stride : 0u) + offset + (u32)i) | (neg << 31);
-  }
-}
-
 // buckets[b].ZZ <- 0 (four 16-byte stores per bucket, one per thread): the identity, see ld_xyzz
 __global__ void msm_clear_buckets_kernel(u32x4* buckets, size_t nb) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,8 +134,10 @@ struct AccArgs {
   const u32* vals;          // level 1: point index | sign << 31
   const u32x4* pts_in;      // level >= 2: XYZZ list
   const u32x4* bases;       // level 1: affine device-form bases (96 B each)
-  size_t len;               // entries at this level
-  u32 chunk;                // entries per thread
+  const u32* ctl;           // level 1: the bucket fill's control block (pairs that exist, entries per thread)
+  size_t grid_threads;      // level 1: threads the host sized the partial lists for
+  size_t len;               // level >= 2: entries at this level
+  u32 chunk;                // level >= 2: entries per thread
   u32 offset;               // level >= 2: thread t covers [t*chunk - offset, (t+1)*chunk - offset)
   u32 trash;                // level 1: first key that is not a bucket
   u32 final_level;          // 1: every run goes to its bucket
@@ -336,15 +262,18 @@ PM_DEV void wave_join(const AccArgs& a, size_t wave, bool wave_live, u32 lane, b
 // partial slots per wave.
 __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t nthreads = (a.len + a.chunk - 1) / a.chunk;
+  // the number of pairs and the chunk length come from the bucket fill (zero digits are dropped there): the host
+  // sized the grid for every digit being non-zero, sparser inputs use shorter chunks on the same grid
+  const size_t len = ld_uniform(a.ctl + CTL_M_EFF), chunk = ld_uniform(a.ctl + CTL_CHUNK);
+  const size_t nthreads = (len + chunk - 1) / chunk;
   const bool active = t < nthreads;
   const u32 lane = threadIdx.x & 63u;
   const size_t wave = t >> 6;
-  const size_t lo = t * a.chunk, hi = lo + a.chunk < a.len ? lo + a.chunk : a.len;
+  const size_t lo = t * chunk, hi = lo + chunk < len ? lo + chunk : len;
   u32 prev_key = KEY_INVALID, next_key = KEY_INVALID;
   if (active) {
     if (lo > 0) prev_key = a.keys[lo - 1];
-    if (hi < a.len) next_key = a.keys[hi];
+    if (hi < len) next_key = a.keys[hi];
     if (next_key >= a.trash) next_key = KEY_INVALID;
   }
   u32 cur = KEY_INVALID, head_key = KEY_INVALID;
@@ -418,7 +347,7 @@ __global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs
     }
   }
   if (a.final_level) return;  // a single thread: nothing can be open
-  wave_join(a, wave, (wave << 6) < nthreads, lane, open, through, cur, acc, have_head, head_key, a.head_pts, t);
+  wave_join(a, wave, (wave << 6) < a.grid_threads, lane, open, through, cur, acc, have_head, head_key, a.head_pts, t);
 }
 
 // Level >= 2: a list of (key | PART_OL | PART_OR, XYZZ) partials in key order, with holes
@@ -642,29 +571,22 @@ static XYZZ projective_to_xyzz(const uint64_t* xyz) {  // homogeneous (X/Z, Y/Z)
   return r;
 }
 
-// ------------------------------------------------------------------ 2: sort
-// rocPRIM's onesweep radix sort with the digit width picked for the key length: the tuned default sorts 8 bits per
-// pass, i.e. three passes for the 20-22 key bits of an MSM.  Measured on 13.6 M (u32 key, u32 value) pairs
-// (profiles/r02_sort_sweep.txt): 20 bits: 388 us default, 268 us with two 10-bit passes (1024 threads x 14 items);
-// 21-22 bits: 388 us default, 321 us with three 9-bit passes (1024 x 8), 342-357 us with two 11-bit passes.
-// Below rocPRIM's merge-sort limit (2^20 items) the configuration does not matter.
-using SortCfg10 = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 14>, rocprim::kernel_config<1024, 14>, 10,
-                                        rocprim::block_radix_rank_algorithm::match>>;
-using SortCfg9 = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
-                                        rocprim::block_radix_rank_algorithm::match>>;
-static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const u32* k_in, u32* k_out, const u32* v_in, u32* v_out, size_t m,
-                             u32 key_bits, hipStream_t st) {
-  if (key_bits <= 20) return rocprim::radix_sort_pairs<SortCfg10>(tmp, tmp_bytes, k_in, k_out, v_in, v_out, m, 0, key_bits, st);
-  if (key_bits <= 27) return rocprim::radix_sort_pairs<SortCfg9>(tmp, tmp_bytes, k_in, k_out, v_in, v_out, m, 0, key_bits, st);
-  return rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, m, 0, key_bits, st);
-}
-
 // ------------------------------------------------------------------ driver
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// PM_MSM_DEBUG=1 in the environment: synchronise after every stage and name it on stderr (localises a device fault)
+static bool msm_debug() {
+  static const bool on = getenv("PM_MSM_DEBUG") != nullptr;
+  return on;
+}
+#define MSM_STAGE(ctx, st, name)                                                \
+  do {                                                                          \
+    if (msm_debug()) {                                                          \
+      fprintf(stderr, "[msm] %s ...", name);                                    \
+      PM_HIP(ctx, hipStreamSynchronize(st));                                    \
+      fprintf(stderr, " done\n");                                               \
+    }                                                                           \
+  } while (0)
 
 int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars, size_t sc_stride,
             u32 batch, u32 scalar_form, uint64_t* out_xyz /* batch x 18 */, hipStream_t st) {
@@ -680,8 +602,10 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     int orc = order_on(ctx, ctx->ord_msm, st);   // msm_ws and the pinned result buffer are shared by all streams
     if (orc) return orc;
   }
-  const MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
-  const size_t m = n * batch * g.nwin;  // (key, value) pairs
+  MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
+  if (g.bins > SORT_MAX_BINS || g.rbits > SORT_MAX_RBITS || g.ts == 0)
+    return set_err(ctx, PM_ERR_BAD_ARG, "window width outside what the bucket fill is laid out for");
+  const size_t m = n * batch * g.nwin;  // (key, value) pairs at most: one per non-zero digit
   const u32 nsets_all = g.nsets * batch;
   if (m > (ctx->opt_msm_max_pairs ? (size_t)ctx->opt_msm_max_pairs : (size_t)0x7fffffffu)) {
     // pair indices are 31-bit: a batch too large for one pass (15 key polynomials of 2^24 coefficients) goes
@@ -748,16 +672,15 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   if (n_levels > 3) return set_err(ctx, PM_ERR_BAD_ARG, "internal: bucket reduction deeper than four levels");
 
   // workspace layout
-  size_t sort_tmp = 0;
-  (void)sort_pairs(nullptr, sort_tmp, nullptr, nullptr, nullptr, nullptr, m, g.key_bits, st);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_keys0 = take(m * 4), o_vals0 = take(m * 4), o_keys1 = take(m * 4), o_vals1 = take(m * 4);
-  const size_t o_sort = take(sort_tmp);
+  // bucket fill: integer scalars + per-tile count rows (histogram -> scatter), partitioned pairs, sorted keys / values
+  const size_t o_canon = take((size_t)n * batch * 32), o_rows = take((size_t)batch * g.tiles * g.bins * 2);
+  const size_t o_pairs = take(m * 8), o_keys1 = take(m * 4 + 4), o_vals1 = take(m * 4 + 4);
   const size_t o_buckets = take(total_buckets * 256);
   std::vector<size_t> o_pkeys(lv.size()), o_ppts(lv.size());
   for (size_t i = 1; i < lv.size(); ++i) {
@@ -774,8 +697,17 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   int rc = ensure_buffer(ctx, ctx->msm_ws, off);
   if (rc) return rc;
   char* ws = (char*)ctx->msm_ws.ptr;
-  u32 *keys0 = (u32*)(ws + o_keys0), *vals0 = (u32*)(ws + o_vals0);
   u32 *keys1 = (u32*)(ws + o_keys1), *vals1 = (u32*)(ws + o_vals1);
+  // control block of the bucket fill: zero when idle (the histogram kernel restores that), zeroed when (re)allocated
+  if (ctx->msm_ctl_cap < g.np) {
+    const u32 cap = std::max<u32>(g.np, 1u << 16);
+    rc = ensure_buffer(ctx, ctx->msm_ctl, sort_ctl_words(cap) * 4);
+    if (rc) return rc;
+    PM_HIP(ctx, hipMemsetAsync(ctx->msm_ctl.ptr, 0, ctx->msm_ctl.bytes, st));
+    ctx->msm_ctl_cap = cap;
+  }
+  g.ctl_cap = ctx->msm_ctl_cap;   // the block's layout is fixed per allocation, whatever this MSM's partition count
+  u32* ctl = (u32*)ctx->msm_ctl.ptr;
   u32x4* buckets = (u32x4*)(ws + o_buckets);
 
   if (ctx->msm_host_pinned_bytes < (size_t)(n_levels + 1) * nsets_all * 256) {
@@ -785,17 +717,41 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, ctx->msm_host_pinned_bytes, hipHostMallocDefault));
   }
 
-  // 1 digits
+  // 1 + 2 bucket fill (msm_sort.cuh)
   {
-  ProfScope prof(ctx, st, "msm_digits");
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n * batch + 255) / 256)), dim3(256), 0, st,
-                     (const u32x4*)d_scalars, n, sc_stride, scalar_form, g, (u32)offset, keys0, vals0);
-  }
-  PM_HIP(ctx, hipGetLastError());
-  // 2 sort
-  {
-    ProfScope prof(ctx, st, "msm_sort_pairs");
-    PM_HIP(ctx, sort_pairs(ws + o_sort, sort_tmp, keys0, keys1, vals0, vals1, m, g.key_bits, st));
+    u32 tiles_per_wg = 1;   // at most ~2 K workgroups: the partition totals cost one atomic per (workgroup-tile, partition)
+    while ((size_t)batch * ((g.tiles + tiles_per_wg - 1) / tiles_per_wg) > 2048) ++tiles_per_wg;
+    const u32 wgs_per_msm = (g.tiles + tiles_per_wg - 1) / tiles_per_wg;
+    const size_t lds1 = sort_scatter_lds(g), lds2 = sort_local_lds(g);
+    const void* k1 = (const void*)msm_digits_scatter_kernel<SORT_THREADS1>;
+    const void* k2 = (const void*)msm_sort_local_kernel;
+    if (ctx->big_lds[k1] < lds1) {
+      PM_HIP(ctx, hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+      ctx->big_lds[k1] = lds1;
+    }
+    if (ctx->big_lds[k2] < lds2) {
+      PM_HIP(ctx, hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      ctx->big_lds[k2] = lds2;
+    }
+    {
+      ProfScope prof(ctx, st, "msm_digits");
+      hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS1>, dim3(batch * wgs_per_msm), dim3(SORT_THREADS1), (size_t)g.bins * 4, st,
+                         (const u32x4*)d_scalars, n, sc_stride, scalar_form, g, tiles_per_wg, wgs_per_msm, (u32)l1_threads,
+                         ctx->opt_msm_chunk ? L1 : 16u, ctl, (u32x4*)(ws + o_canon), (unsigned short*)(ws + o_rows));
+      MSM_STAGE(ctx, st, "digits histogram");
+      hipLaunchKernelGGL(msm_digits_scatter_kernel<SORT_THREADS1>, dim3(batch * g.tiles), dim3(SORT_THREADS1), lds1, st,
+                         (const u32x4*)(ws + o_canon), (const unsigned short*)(ws + o_rows), n, g, (u32)offset, ctl,
+                         (u64*)(ws + o_pairs));
+      MSM_STAGE(ctx, st, "digits scatter");
+    }
+    PM_HIP(ctx, hipGetLastError());
+    {
+      ProfScope prof(ctx, st, "msm_sort_pairs");
+      hipLaunchKernelGGL(msm_sort_local_kernel, dim3(g.np), dim3(SORT_THREADS), lds2, st, g, (const u32*)ctl,
+                         (const u64*)(ws + o_pairs), keys1, vals1);
+      MSM_STAGE(ctx, st, "local sort");
+    }
+    PM_HIP(ctx, hipGetLastError());
   }
   // 3 accumulate
   // empty buckets = the identity = ZZ all zero: only that quarter of every 256-byte record is cleared
@@ -806,6 +762,8 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   memset(&a, 0, sizeof a);
   a.bases = (const u32x4*)(bases->table_c ? bases->d_table : bases->d_xy);
   a.trash = g.trash;
+  a.ctl = ctl;
+  a.grid_threads = l1_threads;
   a.buckets = buckets;
   a.head_pts = (u32x4*)(ws + o_heads);
   for (size_t lvl = 0; lvl < lv.size(); ++lvl) {
@@ -825,7 +783,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
       a.part_keys = (u32*)(ws + o_pkeys[lvl + 1]);
       a.part_pts = (u32x4*)(ws + o_ppts[lvl + 1]);
     }
-    const size_t nthr = (a.len + a.offset + a.chunk - 1) / a.chunk;
+    const size_t nthr = lvl == 0 ? l1_threads : (a.len + a.offset + a.chunk - 1) / a.chunk;
     const unsigned blocks = (unsigned)((nthr + 127) / 128);
     if (lvl > 0 && last && nthr > 64) return set_err(ctx, PM_ERR_BAD_ARG, "internal: final MSM level wider than a wave");
     {
@@ -834,6 +792,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
         hipLaunchKernelGGL(msm_accumulate_l1_kernel, dim3(blocks), dim3(128), 0, st, a);
       else
         hipLaunchKernelGGL(msm_accumulate_ln_kernel, dim3(blocks), dim3(128), 0, st, a);
+      MSM_STAGE(ctx, st, lvl == 0 ? "accumulate level 1" : "accumulate level n");
     }
     PM_HIP(ctx, hipGetLastError());
   }
