@@ -735,13 +735,13 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
     {
       ProfScope prof(ctx, st, "msm_digits");
-      hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS1>, dim3(batch * wgs_per_msm), dim3(SORT_THREADS1), (size_t)g.bins * 4, st,
+      hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS0>, dim3(batch * wgs_per_msm), dim3(SORT_THREADS0), (size_t)g.bins * 4, st,
                          (const u32x4*)d_scalars, n, sc_stride, scalar_form, g, tiles_per_wg, wgs_per_msm, (u32)l1_threads,
                          ctx->opt_msm_chunk ? L1 : 16u, ctl, (u32x4*)(ws + o_canon), (unsigned short*)(ws + o_rows));
       MSM_STAGE(ctx, st, "digits histogram");
-      hipLaunchKernelGGL(msm_digits_scatter_kernel<SORT_THREADS1>, dim3(batch * g.tiles), dim3(SORT_THREADS1), lds1, st,
-                         (const u32x4*)(ws + o_canon), (const unsigned short*)(ws + o_rows), n, g, (u32)offset, ctl,
-                         (u64*)(ws + o_pairs));
+      hipLaunchKernelGGL(msm_digits_scatter_kernel<SORT_THREADS1>, dim3(std::min<u32>(batch * g.tiles, (u32)ctx->num_cus)),
+                         dim3(SORT_THREADS1), lds1, st, (const u32x4*)(ws + o_canon), (const unsigned short*)(ws + o_rows), n, g,
+                         (u32)offset, ctl, (u64*)(ws + o_pairs), batch * g.tiles);
       MSM_STAGE(ctx, st, "digits scatter");
     }
     PM_HIP(ctx, hipGetLastError());

@@ -38,7 +38,11 @@ static constexpr u32 SORT_THREADS = 1024;        // local sort: 16 waves
 #ifndef SORT_T1
 #define SORT_T1 1024
 #endif
-static constexpr u32 SORT_THREADS1 = SORT_T1;    // histogram / scatter kernels: threads = scalars per tile at most
+static constexpr u32 SORT_THREADS1 = SORT_T1;    // scatter kernel: threads = scalars per tile at most
+#ifndef SORT_T0
+#define SORT_T0 256
+#endif
+static constexpr u32 SORT_THREADS0 = SORT_T0;    // histogram kernel (a tile is walked in steps of this many scalars)
 static constexpr u32 SORT_TILE1_PAIRS = 14 * SORT_THREADS1;   // scatter kernel: pairs staged per tile (8 B each in LDS)
 static constexpr u32 SORT_IPT = 16;              // local sort: pairs per thread and tile
 static constexpr u32 SORT_TILE2_PAIRS = SORT_THREADS * SORT_IPT;
@@ -57,7 +61,12 @@ struct MsmGeom {
   // the sort plan
   u32 pbits;     // P: bits of the bucket index that select the partition
   u32 rbits;     // R = bbits - P: bits left for the local sort
-  u32 bins;      // partitions per MSM of the batch: nsets << P
+  u32 sa;        // table mode: the buckets below a_size (the short TOP window's digits land there, on top of every
+  u32 a_size;    //   other window's share) are cut into partitions 2^sa times narrower; 0 = one width everywhere
+  u32 na;        // partitions below a_size
+  u32 na_off;    // na - (a_size >> R): what the narrow region adds to the partition index of the rest
+  u32 pps;       // partitions per bucket set: (1 << P) + na_off
+  u32 bins;      // partitions per MSM of the batch: nsets * pps
   u32 np;        // partitions in all: batch * bins
   u32 ts;        // scalars per tile of the histogram / scatter kernels
   u32 tiles;     // tiles per MSM of the batch
@@ -100,7 +109,29 @@ static inline MsmGeom make_geom(size_t n, long opt_c, u32 table_c, size_t table_
   if (p < p_min) p = p_min;
   g.pbits = p;
   g.rbits = g.bbits - p;
-  g.bins = g.nsets << p;
+  // With the window table every window feeds ONE bucket set, and the top window is short (c = 20: 16 bits, digits
+  // below 2^15 of 2^19 buckets): the low buckets carry (windows - 1) / 2^bbits + 1 / 2^tb of the pairs each instead
+  // of (windows - 1) / 2^bbits -- 2.3 times the others for c = 20, 24 times for c = 22.  Partitions of equal width
+  // would make 64 (c = 22: 8) workgroups of the local sort run two (ten) tiles while the rest run one; the low
+  // region is cut 2^sa times finer instead, so that every partition holds about the same number of pairs.
+  g.sa = g.a_size = g.na = g.na_off = 0;
+  if (table_c && g.nwin > 1 && p >= 1) {
+    const u32 tbits = 256 - g.c * (g.nwin - 1);   // bits of the top window; the scalar is below 2^255
+    if (tbits < g.c && tbits >= 2 && tbits - 1 >= g.rbits) {
+      const u32 tb = tbits - 1;
+      const double ratio = 1.0 + (double)(1u << (g.bbits - tb)) / (double)(g.nwin - 1);
+      u32 sa = 0;
+      while (ratio / (double)(1u << sa) > 1.18 && sa < g.rbits) ++sa;
+      if (sa) {
+        g.sa = sa;
+        g.a_size = 1u << tb;
+        g.na = g.a_size >> (g.rbits - sa);
+        g.na_off = g.na - (g.a_size >> g.rbits);
+      }
+    }
+  }
+  g.pps = (1u << p) + g.na_off;
+  g.bins = g.nsets * g.pps;
   g.np = batch * g.bins;
   g.ts = SORT_TILE1_PAIRS / g.nwin < SORT_THREADS1 ? SORT_TILE1_PAIRS / g.nwin : SORT_THREADS1;
   g.tiles = (u32)((n + g.ts - 1) / g.ts);
@@ -123,6 +154,20 @@ __device__ unsigned long long sort_span[3][4096][2];   // [kernel][workgroup]: f
 #else
 #define SORT_T(kern, i)
 #endif
+
+// partition of a bucket inside its set, and back: first bucket and bucket-index bits of a partition
+PM_DEV u32 part_of(const MsmGeom& g, u32 bucket) {
+  return bucket < g.a_size ? bucket >> (g.rbits - g.sa) : g.na_off + (bucket >> g.rbits);
+}
+PM_DEV void part_range(const MsmGeom& g, u32 pl, u32& first_bucket, u32& bits) {
+  if (pl < g.na) {
+    bits = g.rbits - g.sa;
+    first_bucket = pl << bits;
+  } else {
+    bits = g.rbits;
+    first_bucket = (pl - g.na_off) << bits;
+  }
+}
 
 // ------------------------------------------------------------------ shared pieces
 // A wave-uniform word that an earlier kernel wrote (partition offsets, the pair count), read with an agent-scope
@@ -203,6 +248,40 @@ PM_DEV void for_each_digit(const u32 (&w)[8], u32 c, u32 nwin, F&& emit) {
   }
 }
 
+// The same for a window width known at compile time: every shift and word index is a constant, no loop control (the
+// generic walk above costs ~40 instruction slots per window, three times this one; the digit walk is the largest
+// part of both digit kernels).  The widths the library picks by itself (13, 16, 20 with a table; 22 as an option) get
+// this form, anything else the generic one.
+template <u32 C, class F>
+PM_DEV void for_each_digit_c(const u32 (&w)[8], F&& emit) {
+  constexpr u32 NW = (256 + C - 1) / C, MASK = (1u << C) - 1u, HALF = 1u << (C - 1);
+  u32 carry = 0;
+#pragma unroll
+  for (u32 k = 0; k < NW; ++k) {
+    const u32 lo = k * C, j = lo >> 5, sh = lo & 31u;
+    u32 d = w[j] >> sh;
+    if (sh + C > 32 && j + 1 < 8) d |= w[j + 1] << (32 - sh);
+    d = (d & MASK) + carry;
+    u32 neg = 0;
+    if (d > HALF) {
+      d = (1u << C) - d;
+      neg = 1;
+    }
+    carry = neg;
+    emit(k, d, neg);
+  }
+}
+template <class F>
+PM_DEV void digits(const u32 (&w)[8], u32 c, u32 nwin, F&& emit) {
+  switch (c) {
+    case 13: for_each_digit_c<13>(w, emit); break;
+    case 16: for_each_digit_c<16>(w, emit); break;
+    case 20: for_each_digit_c<20>(w, emit); break;
+    case 22: for_each_digit_c<22>(w, emit); break;
+    default: for_each_digit(w, c, nwin, emit);
+  }
+}
+
 // ------------------------------------------------------------------ 1: histogram + partition offsets
 // Per tile of g.ts scalars: the integer form of every scalar (kept for the scatter kernel: the Montgomery -> integer
 // product and the canonical packing are ~350 of the ~600 instructions a scalar costs here, and both kernels are
@@ -224,22 +303,25 @@ __global__ void __launch_bounds__(NT) msm_digits_hist_kernel(const u32x4* scalar
     SORT_T(0, 0);
     for (u32 b = tid; b < g.bins; b += NT) lds_hist[b] = 0;
     __syncthreads();
-    const size_t i = (size_t)t * g.ts + tid;
-    if (tid < g.ts && i < n) {
-      Fr s = fe_load<FrP>(scalars + 2 * ((size_t)j * sc_stride + i));
-      // Montgomery (x * 2^256): multiply by 2^5 / 2^261 -> x.   Canonical: multiply by one -> x mod r.
-      if (scalar_form == PM_SCALAR_MONTGOMERY)
-        s = fe_mul_limb<FrP>(s, 32u);
-      else
-        s = fe_mul<FrP>(s, fe_one<FrP>());
-      u32 w[8];
-      fe_canon_pack<FrP>(w, s);
-      u32x4* co = canon + 2 * ((size_t)j * n + i);
-      co[0] = u32x4{w[0], w[1], w[2], w[3]};
-      co[1] = u32x4{w[4], w[5], w[6], w[7]};
-      for_each_digit(w, g.c, g.nwin, [&](u32 k, u32 d, u32) {
-        if (d) atomicAdd(&lds_hist[((g.nsets == 1 ? 0u : k) << g.pbits) | ((d - 1) >> g.rbits)], 1u);
-      });
+    for (u32 q0 = 0; q0 < g.ts; q0 += NT) {   // NT threads per tile of g.ts scalars (several workgroups per CU: the
+      const u32 si = q0 + tid;                // loads of one hide behind the arithmetic of the others)
+      const size_t i = (size_t)t * g.ts + si;
+      if (si < g.ts && i < n) {
+        Fr s = fe_load<FrP>(scalars + 2 * ((size_t)j * sc_stride + i));
+        // Montgomery (x * 2^256): multiply by 2^5 / 2^261 -> x.   Canonical: multiply by one -> x mod r.
+        if (scalar_form == PM_SCALAR_MONTGOMERY)
+          s = fe_mul_limb<FrP>(s, 32u);
+        else
+          s = fe_mul<FrP>(s, fe_one<FrP>());
+        u32 w[8];
+        fe_canon_pack<FrP>(w, s);
+        u32x4* co = canon + 2 * ((size_t)j * n + i);
+        co[0] = u32x4{w[0], w[1], w[2], w[3]};
+        co[1] = u32x4{w[4], w[5], w[6], w[7]};
+        digits(w, g.c, g.nwin, [&](u32 k, u32 d, u32) {
+          if (d) atomicAdd(&lds_hist[(g.nsets == 1 ? 0u : k) * g.pps + part_of(g, d - 1)], 1u);
+        });
+      }
     }
     __syncthreads();
     SORT_T(0, 1);
@@ -307,86 +389,103 @@ __global__ void __launch_bounds__(NT) msm_digits_hist_kernel(const u32x4* scalar
 }
 
 // ------------------------------------------------------------------ 2: scatter into the partitions
+// One workgroup per CU (the staged tile fills most of the LDS) walks tiles blockIdx.x, + gridDim.x, ..; the integer
+// scalars and the count row of the NEXT tile are requested before the current one is processed.
 template <u32 NT>
 __global__ void __launch_bounds__(NT) msm_digits_scatter_kernel(const u32x4* canon, const unsigned short* rows, size_t n,
-                                                                          const MsmGeom g, u32 offset, u32* ctl, u64* pairs) {
+                                                                const MsmGeom g, u32 offset, u32* ctl, u64* pairs,
+                                                                u32 tiles_total) {
   extern __shared__ u32 lds_sc[];   // [bins, rounded up to even] counts -> cursors -> deltas, then the staged pairs
   __shared__ u32 wsum[NT / 64];
+  constexpr u32 NQ = SORT_MAX_BINS / NT;
   const u32 tid = threadIdx.x;
-  const u32 j = blockIdx.x / g.tiles, t = blockIdx.x % g.tiles;
   u32* hist = lds_sc;
   u64* stage = reinterpret_cast<u64*>(lds_sc + ((g.bins + 1) & ~1u));
-  SORT_T(1, 0);
-  const size_t i = (size_t)t * g.ts + tid;
-  const bool live = tid < g.ts && i < n;
-  u32x4 wa = u32x4{0u, 0u, 0u, 0u}, wb = wa;
-  if (live) {
-    const u32x4* ci = canon + 2 * ((size_t)j * n + i);
-    wa = ci[0];
-    wb = ci[1];
-  }
-  // one returning atomic per non-empty (tile, partition): the range this tile's run goes to (its latency hides
-  // behind the scan and the LDS pass below: the result is first needed for the deltas)
-  const unsigned short* row = rows + ((size_t)j * g.tiles + t) * g.bins;
   u32* cursor = ctl + CTL_HEADER + 2 * (size_t)g.ctl_cap + 1;
-  constexpr u32 NQ = SORT_MAX_BINS / NT;
-  u32 gb[NQ];
-#pragma unroll
-  for (u32 q = 0; q < NQ; ++q) {
-    const u32 b = tid + q * NT;
-    gb[q] = 0;
-    if (b < g.bins) {
-      const u32 v = row[b];
-      hist[b] = v;
-      if (v) gb[q] = atomicAdd(&cursor[(size_t)j * g.bins + b], v);
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+  u32x4 wa = zero4, wb = zero4;
+  u32 rv[NQ];
+  auto fetch = [&](u32 tile, u32x4& a_, u32x4& b_, u32 (&r_)[NQ]) {
+    const u32 j_ = tile / g.tiles, t_ = tile % g.tiles;
+    const size_t i_ = (size_t)t_ * g.ts + tid;
+    a_ = zero4;
+    b_ = zero4;
+    if (tid < g.ts && i_ < n) {
+      const u32x4* ci = canon + 2 * ((size_t)j_ * n + i_);
+      a_ = ci[0];
+      b_ = ci[1];
     }
-  }
-  __syncthreads();
-  SORT_T(1, 1);
-  const u32 total = block_exclusive_scan<NT>(hist, g.bins, wsum);
-  SORT_T(1, 2);
-  if (live) {
-    const u32 w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    for_each_digit(w, g.c, g.nwin, [&](u32 k, u32 d, u32 neg) {
-      if (d) {
-        const u32 set_local = g.nsets == 1 ? 0u : k;
-        const u32 pos = atomicAdd(&hist[(set_local << g.pbits) | ((d - 1) >> g.rbits)], 1u);
-        const u32 key = ((j * g.nsets + set_local) << g.bbits) | (d - 1);
-        // table of 2^(c k) P (nsets == 1): every window feeds the one bucket set of its MSM
-        const u32 val = ((g.nsets == 1 ? k * g.row_stride : 0u) + offset + (u32)i) | (neg << 31);
-        stage[pos] = ((u64)key << 32) | val;
+    const unsigned short* row = rows + (size_t)tile * g.bins;
+#pragma unroll
+    for (u32 q = 0; q < NQ; ++q) {
+      const u32 b = tid + q * NT;
+      r_[q] = b < g.bins ? row[b] : 0u;
+    }
+  };
+  u32 tile = blockIdx.x;
+  if (tile < tiles_total) fetch(tile, wa, wb, rv);
+  for (; tile < tiles_total; tile += gridDim.x) {
+    const u32 j = tile / g.tiles, t = tile % g.tiles;
+    const size_t i = (size_t)t * g.ts + tid;
+    const bool live = tid < g.ts && i < n;
+    SORT_T(1, 0);
+    // one returning atomic per non-empty (tile, partition): the range this tile's run goes to (its latency hides
+    // behind the scan and the LDS pass below: the result is first needed for the deltas)
+    u32 gb[NQ];
+#pragma unroll
+    for (u32 q = 0; q < NQ; ++q) {
+      const u32 b = tid + q * NT;
+      gb[q] = 0;
+      if (b < g.bins) {
+        hist[b] = rv[q];
+        if (rv[q]) gb[q] = atomicAdd(&cursor[(size_t)j * g.bins + b], rv[q]);
       }
-    });
-  }
-  __syncthreads();
-  SORT_T(1, 3);
-  // hist[b] is now the END of bin b in the staged tile; delta[b] = reserved range - start of the bin
-  u32 st[NQ];
+    }
+    const u32 w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    if (tile + gridDim.x < tiles_total) fetch(tile + gridDim.x, wa, wb, rv);   // the next tile: in flight from here on
+    __syncthreads();
+    SORT_T(1, 1);
+    const u32 total = block_exclusive_scan<NT>(hist, g.bins, wsum);
+    SORT_T(1, 2);
+    if (live) {
+      digits(w, g.c, g.nwin, [&](u32 k, u32 d, u32 neg) {
+        if (d) {
+          const u32 set_local = g.nsets == 1 ? 0u : k;
+          const u32 pos = atomicAdd(&hist[set_local * g.pps + part_of(g, d - 1)], 1u);
+          const u32 key = ((j * g.nsets + set_local) << g.bbits) | (d - 1);
+          // table of 2^(c k) P (nsets == 1): every window feeds the one bucket set of its MSM
+          const u32 val = ((g.nsets == 1 ? k * g.row_stride : 0u) + offset + (u32)i) | (neg << 31);
+          stage[pos] = ((u64)key << 32) | val;
+        }
+      });
+    }
+    __syncthreads();
+    SORT_T(1, 3);
+    // hist[b] is now the END of bin b in the staged tile; delta[b] = reserved range - start of the bin
+    u32 st[NQ];
 #pragma unroll
-  for (u32 q = 0; q < NQ; ++q) {
-    const u32 b = tid + q * NT;
-    st[q] = (b < g.bins && b > 0) ? hist[b - 1] : 0u;
-  }
-  __syncthreads();
+    for (u32 q = 0; q < NQ; ++q) {
+      const u32 b = tid + q * NT;
+      st[q] = (b < g.bins && b > 0) ? hist[b - 1] : 0u;
+    }
+    __syncthreads();
 #pragma unroll
-  for (u32 q = 0; q < NQ; ++q) {
-    const u32 b = tid + q * NT;
-    if (b < g.bins) hist[b] = gb[q] - st[q];
+    for (u32 q = 0; q < NQ; ++q) {
+      const u32 b = tid + q * NT;
+      if (b < g.bins) hist[b] = gb[q] - st[q];
+    }
+    __syncthreads();
+    SORT_T(1, 4);
+    for (u32 e = tid; e < total; e += NT) {
+      const u64 pr = stage[e];
+      const u32 key = (u32)(pr >> 32);
+      const u32 set_local = (key >> g.bbits) - j * g.nsets;
+      const u32 bin = set_local * g.pps + part_of(g, key & (g.nbuckets - 1u));
+      pairs[hist[bin] + e] = pr;
+    }
+    __syncthreads();   // the next tile overwrites hist[] and the stage
+    SORT_T(1, 5);
   }
-  __syncthreads();
-  SORT_T(1, 4);
-  for (u32 e = tid; e < total; e += NT) {
-    const u64 pr = stage[e];
-    const u32 key = (u32)(pr >> 32);
-    const u32 set_local = (key >> g.bbits) - j * g.nsets;
-    const u32 bin = (set_local << g.pbits) | ((key & (g.nbuckets - 1u)) >> g.rbits);
-    pairs[hist[bin] + e] = pr;
-  }
-#ifdef SORT_TIMING
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  SORT_T(1, 5);
-#endif
 }
 
 // ------------------------------------------------------------------ 3: counting sort inside a partition
@@ -399,18 +498,33 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
   const u32* startp = ctl + CTL_HEADER + g.ctl_cap;
   const u32 lo = ld_uniform(startp + p), size = ld_uniform(startp + p + 1) - lo;
   if (size == 0) return;
-  const u32 nb = 1u << g.rbits, lmask = nb - 1u;
+  u32 first_bucket, pr_bits;
+  part_range(g, p % g.pps, first_bucket, pr_bits);
+  const u32 nb = 1u << pr_bits, lmask = nb - 1u;
   u32* cur = lds_ls;
   u32* thist = cur + nb;
   u32* stage_v = thist + nb;
   unsigned short* stage_k = reinterpret_cast<unsigned short*>(stage_v + SORT_TILE2_PAIRS);
-  const u32 key_hi = p << g.rbits;
+  const u32 key_hi = ((p / g.pps) << g.bbits) | first_bucket;
   const u32 ntile = (size + SORT_TILE2_PAIRS - 1) / SORT_TILE2_PAIRS;
   const u64* src = pairs + lo;
   if (ntile > 1) {   // streamed partition: bucket counts over the whole partition first
     for (u32 b = tid; b < nb; b += SORT_THREADS) cur[b] = 0;
     __syncthreads();
-    for (u32 e = tid; e < size; e += SORT_THREADS) atomicAdd(&cur[(u32)(src[e] >> 32) & lmask], 1u);
+    for (u32 e0 = 0; e0 < size; e0 += SORT_THREADS) {
+      const u32 e = e0 + tid;
+      const bool on = e < size;
+      const u32 b = on ? (u32)(src[e] >> 32) & lmask : 0u;
+      // a wave whose lanes all hit ONE bucket (all-equal scalars, a dominant value) adds once: 64 atomics on one
+      // LDS word are served one after the other
+      const u64 act = __ballot(on);
+      const u32 b0 = __shfl(b, act ? __ffsll((long long)act) - 1 : 0);
+      if (__ballot(on && b == b0) == act) {
+        if (on && (tid & 63u) == (u32)(__ffsll((long long)act) - 1)) atomicAdd(&cur[b0], (u32)__popcll(act));
+      } else if (on) {
+        atomicAdd(&cur[b], 1u);
+      }
+    }
     __syncthreads();
     (void)block_exclusive_scan(cur, nb, wsum);
   }
@@ -430,9 +544,42 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
     __syncthreads();
     SORT_T(2, 1);
     u32 rk[SORT_IPT];
+    {
+      // ranks inside the tile from LDS atomics.  A wave whose pairs ALL carry one bucket (all-equal scalars, a
+      // dominant value) takes one atomic for the lot -- 64 adds to one LDS word are served one after the other --
+      // tested once per tile, not per pair
+      u32 mine = 0, x = lk[0];
+      bool same = true;
 #pragma unroll
-    for (u32 q = 0; q < SORT_IPT; ++q)
-      if (tid + q * SORT_THREADS < cnt) rk[q] = atomicAdd(&thist[lk[q]], 1u);
+      for (u32 q = 0; q < SORT_IPT; ++q)
+        if (tid + q * SORT_THREADS < cnt) {
+          same = same && lk[q] == x;
+          ++mine;
+        }
+      const u32 lane = tid & 63u;
+      const u64 act = __ballot(mine != 0);
+      const u32 first = act ? (u32)__ffsll((long long)act) - 1u : 0u;
+      const u32 x0 = __shfl(x, first);
+      if (act && __ballot(same && (mine == 0 || x == x0)) == ~0ull) {
+        u32 inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const u32 t_ = __shfl_up(inc, d);
+          if ((int)lane >= d) inc += t_;
+        }
+        const u32 tot = __shfl(inc, 63);
+        u32 base = 0;
+        if (lane == first) base = atomicAdd(&thist[x0], tot);
+        u32 run = __shfl(base, first) + inc - mine;
+#pragma unroll
+        for (u32 q = 0; q < SORT_IPT; ++q)
+          if (tid + q * SORT_THREADS < cnt) rk[q] = run++;
+      } else {
+#pragma unroll
+        for (u32 q = 0; q < SORT_IPT; ++q)
+          if (tid + q * SORT_THREADS < cnt) rk[q] = atomicAdd(&thist[lk[q]], 1u);
+      }
+    }
     __syncthreads();
     SORT_T(2, 2);
     (void)block_exclusive_scan(thist, nb, wsum);

@@ -122,7 +122,7 @@ static bool run_case(const Case& cs, int reps, bool full_check) {
   CK(hipFuncSetAttribute((const void*)msm_sort_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
   {
     int o0 = 0, o1 = 0, o2 = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, msm_digits_hist_kernel<SORT_THREADS1>, SORT_THREADS1, lds0));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, msm_digits_hist_kernel<SORT_THREADS0>, SORT_THREADS0, lds0));
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, msm_digits_scatter_kernel<SORT_THREADS1>, SORT_THREADS1, lds1));
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, msm_sort_local_kernel, SORT_THREADS, lds2));
     printf("      occupancy (workgroups per CU, API): hist %d scatter %d local %d; LDS %zu / %zu / %zu B\n", o0, o1, o2, lds0, lds1, lds2);
@@ -132,12 +132,12 @@ static bool run_case(const Case& cs, int reps, bool full_check) {
   float t0 = 0, t1 = 0, t2 = 0;
   for (int r = 0; r < reps + 1; ++r) {
     CK(hipEventRecord(ev[0], 0));
-    hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS1>, dim3(cs.batch * wgs_per_msm), dim3(SORT_THREADS1), lds0, 0, (const u32x4*)d_sc, n, n,
+    hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS0>, dim3(cs.batch * wgs_per_msm), dim3(SORT_THREADS0), lds0, 0, (const u32x4*)d_sc, n, n,
                        (u32)PM_SCALAR_CANONICAL, g, tiles_per_wg, wgs_per_msm, 131072u, 16u, (u32*)d_ctl, (u32x4*)d_canon,
                        (unsigned short*)d_rows);
     CK(hipEventRecord(ev[1], 0));
-    hipLaunchKernelGGL(msm_digits_scatter_kernel<SORT_THREADS1>, dim3(tiles_total), dim3(SORT_THREADS1), lds1, 0, (const u32x4*)d_canon,
-                       (const unsigned short*)d_rows, n, g, 0u, (u32*)d_ctl, (u64*)d_pairs);
+    hipLaunchKernelGGL(msm_digits_scatter_kernel<SORT_THREADS1>, dim3(std::min<uint32_t>(tiles_total, 256)), dim3(SORT_THREADS1), lds1, 0,
+                       (const u32x4*)d_canon, (const unsigned short*)d_rows, n, g, 0u, (u32*)d_ctl, (u64*)d_pairs, tiles_total);
     CK(hipEventRecord(ev[2], 0));
     hipLaunchKernelGGL(msm_sort_local_kernel, dim3(g.np), dim3(SORT_THREADS), lds2, 0, g, (const u32*)d_ctl, (const u64*)d_pairs,
                        (u32*)d_keys, (u32*)d_vals);
