@@ -98,15 +98,16 @@ PM_DEV Xyzz xyzz_madd(const Xyzz& acc, const Fp& x2, const Fp& y2) {
   Fp R = fe_norm<FpP>(fe_sub<FpP, 6, 1>(S2, acc.y));       // (1+, <8)
   Fp PP, RR;
   fe_sqr2<FpP>(P, R, PP, RR);
+  // PPP = P PP, Q = X1 PP and ZZ3 = ZZ1 PP: three independent products, three chains
   Fp PPP, Q;
-  fe_mul2<FpP>(P, PP, acc.x, PP, PPP, Q);
+  fe_mul3<FpP>(P, PP, acc.x, PP, acc.zz, PP, PPP, Q, r.zz);
   Fp t = fe_sub<FpP, 3, 1>(RR, PPP);                       // (4, <5)
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
   Fp D = fe_sub<FpP, 11, 1>(Q, r.x);                       // (4, <13)
-  Fp YA, YB;
-  fe_mul2<FpP>(R, D, acc.y, PPP, YA, YB);
-  r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));           // (1+, <5)
-  fe_mul2<FpP>(acc.zz, PP, acc.zzz, PPP, r.zz, r.zzz);
+  // Y3 = R D - Y1 PPP as R D + (6 p - Y1) PPP with ONE reduction (fe_mma2: 1 x 4 + 3 x 1 = 7 < 17 in the column
+  // bound, value < (8 x 13 + 6 x 2) p^2 / R' + p < 1.05 p), in lock step with ZZZ3 = ZZZ1 PPP
+  const Fp nY1 = fe_sub<FpP, 6, 1>(fe_zero<FpP>(), acc.y);  // (3, <6)
+  fe_mma2<FpP>(R, D, nY1, PPP, acc.zzz, PPP, r.y, r.zzz);  // Y3 (1, <2)
   r.inf = false;
   if (fp_is_zero_product(r.zz)) {  // same x: acc == +-(x2, y2)
     if (fp_is_zero_lazy(R))
@@ -129,17 +130,16 @@ PM_DEV Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
   Fp R = fe_norm<FpP>(fe_sub<FpP, 3, 1>(S2, S1));          // (1+, <5)
   Fp PP, RR;
   fe_sqr2<FpP>(P, R, PP, RR);
-  Fp PPP, Q;
+  Fp PPP, Q, z12, zzz12;
   fe_mul2<FpP>(P, PP, U1, PP, PPP, Q);
+  fe_mul2<FpP>(a.zz, b.zz, a.zzz, b.zzz, z12, zzz12);
   Fp t = fe_sub<FpP, 3, 1>(RR, PPP);
   r.x = fe_norm<FpP>(fe_sub<FpP, 5, 1>(t, fe_add<FpP>(Q, Q)));   // (1+, <10)
   Fp D = fe_sub<FpP, 11, 1>(Q, r.x);
-  Fp YA, YB;
-  fe_mul2<FpP>(R, D, S1, PPP, YA, YB);
-  r.y = fe_norm<FpP>(fe_sub<FpP, 3, 1>(YA, YB));           // (1+, <5)
-  Fp z12, zzz12;
-  fe_mul2<FpP>(a.zz, b.zz, a.zzz, b.zzz, z12, zzz12);
-  fe_mul2<FpP>(z12, PP, zzz12, PPP, r.zz, r.zzz);
+  // Y3 = R D - S1 PPP with one reduction (S1 is a product: (1, <2), so 3 p - S1 has limbs < 3 x 2^28), next to ZZ3
+  const Fp nS1 = fe_sub<FpP, 3, 1>(fe_zero<FpP>(), S1);     // (3, <3)
+  fe_mma2<FpP>(R, D, nS1, PPP, z12, PP, r.y, r.zz);         // Y3 (1, <2)
+  r.zzz = fe_mul<FpP>(zzz12, PPP);
   r.inf = false;
   if (fp_is_zero_product(r.zz)) {
     if (fp_is_zero_lazy(R))

@@ -381,6 +381,135 @@ PM_DEV void fe_mul2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<
   r0.l[N - 1] = (u32)acc0;
   r1.l[N - 1] = (u32)acc1;
 }
+// Three independent products in lock step (the third chain of a round that has three products to offer).
+template <class P>
+PM_DEV void fe_mul3(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, const Fe<P>& a2, const Fe<P>& b2,
+                    Fe<P>& r0, Fe<P>& r1, Fe<P>& r2) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q0[N], q1[N], q2[N];
+  u64 acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      acc0 += (u64)a0.l[i] * b0.l[k - i];
+      acc1 += (u64)a1.l[i] * b1.l[k - i];
+      acc2 += (u64)a2.l[i] * b2.l[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) {
+      acc0 += (u64)q0[i] * M.v[k - i];
+      acc1 += (u64)q1[i] * M.v[k - i];
+      acc2 += (u64)q2[i] * M.v[k - i];
+    }
+    if (M.v[0] == 1u) {
+      q0[k] = (0u - (u32)acc0) & MASK;
+      q1[k] = (0u - (u32)acc1) & MASK;
+      q2[k] = (0u - (u32)acc2) & MASK;
+      acc0 += q0[k];
+      acc1 += q1[k];
+      acc2 += q2[k];
+    } else {
+      q0[k] = ((u32)acc0 * NINV) & MASK;
+      q1[k] = ((u32)acc1 * NINV) & MASK;
+      q2[k] = ((u32)acc2 * NINV) & MASK;
+      acc0 += (u64)q0[k] * M.v[0];
+      acc1 += (u64)q1[k] * M.v[0];
+      acc2 += (u64)q2[k] * M.v[0];
+    }
+    acc0 >>= W;
+    acc1 >>= W;
+    acc2 >>= W;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      acc0 += (u64)a0.l[i] * b0.l[k - i];
+      acc1 += (u64)a1.l[i] * b1.l[k - i];
+      acc2 += (u64)a2.l[i] * b2.l[k - i];
+    }
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      acc0 += (u64)q0[i] * M.v[k - i];
+      acc1 += (u64)q1[i] * M.v[k - i];
+      acc2 += (u64)q2[i] * M.v[k - i];
+    }
+    r0.l[k - N] = (u32)acc0 & MASK;
+    r1.l[k - N] = (u32)acc1 & MASK;
+    r2.l[k - N] = (u32)acc2 & MASK;
+    acc0 >>= W;
+    acc1 >>= W;
+    acc2 >>= W;
+  }
+  r0.l[N - 1] = (u32)acc0;
+  r1.l[N - 1] = (u32)acc1;
+  r2.l[N - 1] = (u32)acc2;
+}
+// r0 = (a0 b0 + c0 d0) / R with ONE reduction for the two products (both go into the same column accumulators: a
+// difference of products costs 3 N^2 limb products instead of 4 N^2 when the subtrahend is negated limb-wise first),
+// in lock step with an ordinary product r1 = a1 b1 / R.  Column bound: N (Ba Bb + Bc Bd) 2^(2W) + (N-1) 2^(2W) +
+// 2^(64-W) < 2^64, i.e. Ba Bb + Bc Bd < 17 for Fp (limb bounds B in units of 2^W); the value is < (a0 b0 + c0 d0) / R + m.
+template <class P>
+PM_DEV void fe_mma2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& c0, const Fe<P>& d0, const Fe<P>& a1, const Fe<P>& b1,
+                    Fe<P>& r0, Fe<P>& r1) {
+  constexpr int N = P::N, W = P::W;
+  constexpr u32 MASK = Consts<P>::MASK;
+  constexpr Limbs<N> M = Consts<P>::mod_limbs();
+  constexpr u32 NINV = Consts<P>::neg_inv();
+  u32 q0[N], q1[N];
+  u64 acc0 = 0, acc1 = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      acc0 += (u64)a0.l[i] * b0.l[k - i];
+      acc1 += (u64)a1.l[i] * b1.l[k - i];
+      acc0 += (u64)c0.l[i] * d0.l[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) {
+      acc0 += (u64)q0[i] * M.v[k - i];
+      acc1 += (u64)q1[i] * M.v[k - i];
+    }
+    if (M.v[0] == 1u) {
+      q0[k] = (0u - (u32)acc0) & MASK;
+      q1[k] = (0u - (u32)acc1) & MASK;
+      acc0 += q0[k];
+      acc1 += q1[k];
+    } else {
+      q0[k] = ((u32)acc0 * NINV) & MASK;
+      q1[k] = ((u32)acc1 * NINV) & MASK;
+      acc0 += (u64)q0[k] * M.v[0];
+      acc1 += (u64)q1[k] * M.v[0];
+    }
+    acc0 >>= W;
+    acc1 >>= W;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      acc0 += (u64)a0.l[i] * b0.l[k - i];
+      acc1 += (u64)a1.l[i] * b1.l[k - i];
+      acc0 += (u64)c0.l[i] * d0.l[k - i];
+    }
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      acc0 += (u64)q0[i] * M.v[k - i];
+      acc1 += (u64)q1[i] * M.v[k - i];
+    }
+    r0.l[k - N] = (u32)acc0 & MASK;
+    r1.l[k - N] = (u32)acc1 & MASK;
+    acc0 >>= W;
+    acc1 >>= W;
+  }
+  r0.l[N - 1] = (u32)acc0;
+  r1.l[N - 1] = (u32)acc1;
+}
 template <class P>
 PM_DEV void fe_sqr2(const Fe<P>& a0, const Fe<P>& a1, Fe<P>& r0, Fe<P>& r1) {
   constexpr int N = P::N, W = P::W;
