@@ -52,6 +52,8 @@ def main():
                     help="skip the PCIe-inclusive and coset-4n NTT measurements (PMC passes: one NTT size only)")
     ap.add_argument("--prover-log-n", type=int, default=20,
                     help="gates of the synthetic circuit for the full-prove entry (BASELINE configs[3])")
+    ap.add_argument("--cpu-prover-log-n", type=int, default=18,
+                    help="gates of the CPU-baseline proof (2^18: ~8 s on 16 threads; 2^20, the GPU leg's size: ~35 s)")
     ap.add_argument("--fourstep-log-n", type=int, default=0,
                     help="N > 1 only, off by default: also time ONE 2^K transform split over the ranks "
                          "(pm_fr_ntt_fourstep_dev, SURVEY 8f N5) through the library's RCCL communicator")
@@ -118,6 +120,13 @@ def main():
         native_comm = bool(flag.item())
         if not native_comm and ok_local:
             ctx.comm_destroy()
+        # self-diagnosing first multi-GPU run: every rank says what communicator it ended up with
+        import ctypes as _C
+        _r, _w = _C.c_int(-1), _C.c_int(-1)
+        ctx._lib.pm_comm_info(ctx._h, _C.byref(_r), _C.byref(_w))
+        print(f"[bench] rank {rank}/{world} device {local_rank}: library communicator "
+              f"{'rank %d of %d' % (_r.value, _w.value) if native_comm else 'NOT in use (torch.distributed ' + backend + ')'}",
+              file=sys.stderr, flush=True)
     stream = torch.cuda.current_stream().cuda_stream
     # host threads we may use: the box's CPU share, not every core the kernel lists
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
@@ -134,34 +143,38 @@ def main():
         ctx.fr_ntt_dev(d_a.data_ptr(), n, d_b.data_ptr(), k, 0, stream=stream)
         ctx.fr_ntt_dev(d_b.data_ptr(), n, d_c.data_ptr(), k, INVERSE, stream=stream)
 
-    # warm-up doubles as a fully profiled pre-run: it names the dominant kernel and gives every kernel's
-    # mean duration; the timed region then keeps the event pair of the dominant kernel only (an event
-    # pair is ~5 us of stream time, and the roofline needs that one kernel's live duration)
+    # the timed region runs with every timer OFF (an event pair is ~5 us of stream time: r02's headline carried the
+    # dominant kernel's pair inside the loop and read 4-9 % low); the kernels' durations -- the roofline needs the
+    # dominant one's -- come from a separate, fully profiled loop of the same step right after it
     step()                                                          # first launches: tables, code load
     barrier()
-    ctx.profile(True)
     for _ in range(max(args.warmup, 1)):
         step()
-    barrier()
-    pre = {name: v for name, v in ctx.profile_read().items() if name.startswith("ntt_pass")}
-    dom = max(pre, key=lambda s_: pre[s_][1])
-    ctx.profile(True, only=dom)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    prof = ctx.profile_read()
-    ctx.profile(False)
     assert torch.equal(d_c, d_a), "iNTT(NTT(a)) != a"            # round trip inside the bench
     butterflies_per_step = 2 * (n // 2) * k
     value = world * butterflies_per_step * args.steps / dt
+    prof_steps = max(20, min(args.steps, 200))
+    ctx.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(prof_steps):
+        step()
+    barrier()
+    dt_prof = (time.perf_counter() - t0) / prof_steps
+    pre = {name: v for name, v in ctx.profile_read().items() if name.startswith("ntt_pass")}
+    ctx.profile(False)
+    dom = max(pre, key=lambda s_: pre[s_][1])
+    prof = pre
 
     # roofline of the dominant kernel: algorithmic bytes of one launch / its mean duration
     passes = pa.ntt_plan(k)
-    kern = dict(pre)
-    kern[dom] = prof[dom]                                          # live, over the timed region
+    kern = dict(pre)                                               # live: the profiled loop of this run
     dom_ms = kern[dom][1] / kern[dom][0]
     s_dom = passes[0] if dom.endswith("first") or dom.endswith("single") else passes[-1]
     algo_bytes = 64 * n * s_dom / k                                # 64 N bytes per transform, S/k of it per pass
@@ -172,7 +185,9 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                 "avg_launch_us": round(dom_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(algo_bytes),
                 "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()},
-                "pmc_evidence": "profiles/r02_pmc_summary.json (offline rocprofv3 --pmc passes of this command)",
+                "measured_in": f"a separate profiled loop of {prof_steps} steps ({dt_prof * 1e3:.4f} ms per step with an event "
+                               f"pair around every kernel); `value` is from the loop with the timers off",
+                "pmc_evidence": "profiles/r03_pmc_summary.json (offline rocprofv3 --pmc passes of this command)",
                 "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
 
     # ------------------------------------------------------------------ NTT extras (rank 0): SURVEY 8d
@@ -321,6 +336,23 @@ def main():
                             "unit": "GB/s", "frac": round(128 * (hi - lo) / (acc_ms * 1e-3) / HBM_PEAK, 5),
                             "traffic": None, "avg_launch_us": round(acc_ms * 1e3, 1),
                             "algorithmic_bytes_per_launch": 128 * (hi - lo)}}
+        if world > 1:
+            # the exchange alone (2312-byte all-gather + fold), timed on every rank: max over ranks
+            xt = None
+            try:
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    if native_comm:
+                        ctx.g1_allgather_fold(res.reshape(1, 18))
+                    else:
+                        allgather_fold(res, coll_dev)
+                xt = max_over_ranks((time.perf_counter() - t0) / 20)
+            except Exception as e:                                   # noqa: BLE001
+                print(f"[bench] rank {rank}: exchange timing failed ({e})", file=sys.stderr)
+            out["exchange_us"] = round(xt * 1e6, 1) if xt is not None else None
+            print(f"[bench] rank {rank}: 2^{mk} MSM shard [{lo}, {hi}) {mdt / steps * 1e3:.3f} ms per MSM, exchange "
+                  f"{out['exchange_us']} us", file=sys.stderr, flush=True)
         assert ok, "MSM result differs from the discrete-log identity"
         if table and world == 1 and not args.no_msm_extra:
             # what an 8-way point shard of this MSM costs on one GPU (its own window table, sized for the
@@ -340,12 +372,34 @@ def main():
             ctx.profile(False)
             sh_bases.free()
             tail = sum(v[1] / v[0] for s_, v in sprof.items() if s_ in ("msm_bucket_chunk", "msm_window_sum", "msm_accumulate_ln"))
-            exch = 30e-6                      # one 2.3 KB ncclAllGather + 7 host additions (not measurable on one GPU)
             out["shard_1_of_8"] = {"points": sh_n, "ms_per_msm": sdt * 1e3,
                                    "kernels_us": {s_: round(v[1] / v[0] * 1e3, 1) for s_, v in sprof.items()},
                                    "tail_frac": round(tail * 1e-3 / sdt, 3),
                                    "note": "tail = partial-list levels + bucket reduction + window sums"}
-            out["projected_scaling_8"] = round((mdt / steps) / (sdt + exch), 2)
+            # NOT a measurement of 8 GPUs: the one-GPU time over (the measured time of a 1/8 shard + the measured
+            # time of the library's exchange on a ONE-rank communicator: staging copies + ncclAllGather + fold)
+            exch = None
+            try:
+                ctx.comm_init(0, 1)
+                ctx.g1_allgather_fold(res.reshape(1, 18))
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    ctx.g1_allgather_fold(res.reshape(1, 18))
+                exch = (time.perf_counter() - t0) / 20
+            except Exception as e:                                   # noqa: BLE001
+                print(f"[bench] one-rank communicator unavailable ({e})", file=sys.stderr)
+            finally:
+                try:
+                    ctx.comm_destroy()
+                except Exception:                                    # noqa: BLE001
+                    pass
+            if exch is not None:
+                out["projection"] = {"scaling_8_gpus": round((mdt / steps) / (sdt + exch), 2),
+                                     "is_a_measurement": False,
+                                     "assumptions": "8 ranks each run a 1/8 point shard with its own window table (shard_1_of_8, "
+                                                    "measured on this GPU), then one pm_g1_allgather_fold; the exchange is priced "
+                                                    "at its measured ONE-rank cost (no xGMI hop, one message instead of eight)",
+                                     "exchange_us_world1": round(exch * 1e6, 1)}
         if table and world == 1 and mk <= 20 and not args.no_msm_extra:
             # "witness-like" scalars: 90 % below 2^16, 5 % zero, 1 % one -- bucket skew and shortcuts
             rs = np.random.default_rng(0x5343414C)
@@ -631,7 +685,7 @@ def main():
             # the same rounds on the host cores: the C restatement composed by oracle/cpu_prover.py, on a
             # bounded sample (a 2^16-gate circuit), outputs compared with a GPU proof of that circuit
             from oracle import cpu_prover as CP
-            ck_ = min(gk, 18)
+            ck_ = min(gk, args.cpu_prover_log_n)
             cn = 1 << ck_
             c_circ, c_wit, c_pub = pa.synthetic.chain_circuit(cn, 2)
             c_srs = pts[:cn]
@@ -644,10 +698,26 @@ def main():
             same = all(np.array_equal(g_proof.commitments[k_], v_) for k_, v_ in c_out["commitments"].items()) and \
                 all(np.array_equal(g_proof.evaluations[k_], v_) for k_, v_ in c_out["evaluations"].items())
             assert same, "GPU proof differs from the CPU restatement's proof"
+            # the reference's own default is ONE thread (default-features = false: no rayon, ref:Cargo.toml:19): the same
+            # prover on one thread, on a smaller sample (2^14 gates) so that the leg stays within its time budget
+            s1k = min(gk, 14)
+            s_circ, s_wit, s_pub = pa.synthetic.chain_circuit(1 << s1k, 3)
+            s_srs = pts[:1 << s1k]
+            s_ck = pa.CommitKey(s_srs, ctx)
+            s_proof = pa.prove(pa.preprocess(s_circ, ctx, s_ck), s_ck, s_wit, s_pub)
+            spk = CP.preprocess(oracle, {k_: getattr(s_circ, k_) for k_ in CP.SELECTORS}, s_circ.sigma_index, 1)
+            t0 = time.perf_counter()
+            CP.prove(oracle, spk, s_srs, s_wit, s_pub, s_proof.challenges, 1)
+            st1 = time.perf_counter() - t0
             prover["cpu_baseline"] = {"value": cn / ct, "unit": "gates/s", "cores": cores, "kind": "port",
                                       "ms_per_proof": round(ct * 1e3, 1), "bit_exact_vs_gpu": bool(same),
                                       "sample": f"one 2^{ck_}-gate proof (5 rounds, 11 Pippenger MSMs, radix-2 NTTs) with "
-                                                f"the C restatement on {cores} threads"}
+                                                f"the C restatement on {cores} threads",
+                                      "single_thread_value": (1 << s1k) / st1,
+                                      "single_thread_sample": f"one 2^{s1k}-gate proof on 1 thread ({st1:.1f} s) -- the reference's "
+                                                              f"default build has no rayon",
+                                      "why_not_full_size": None if ck_ == gk else f"the 2^{gk}-gate proof takes ~{ct * (1 << (gk - ck_)):.0f} s on "
+                                                           f"{cores} threads: outside the bounded-sample budget; pass --cpu-prover-log-n {gk}"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     cpu = None
@@ -684,6 +754,12 @@ def main():
             cpu["msm_value"] = sn / tmsm
             cpu["msm_unit"] = "scalar-muls/s"
             cpu["msm_sample"] = f"one 2^{sk}-point Pippenger MSM (c rule of the reference), {cores} threads"
+            s1n = min(sn, 1 << 17)                         # one thread = the reference's default build; bounded sample
+            t0 = time.perf_counter()
+            cpu_oracle.g1_msm(pts[:s1n], sc[:s1n], 0, 1)
+            t1msm = time.perf_counter() - t0
+            cpu["msm_single_thread_value"] = s1n / t1msm
+            cpu["msm_single_thread_sample"] = f"one 2^{s1n.bit_length() - 1}-point Pippenger MSM on 1 thread ({t1msm:.1f} s)"
 
     if rank == 0:
         out = {"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": value, "unit": "butterflies/s",

@@ -301,10 +301,15 @@ int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_
 #define PM_PLONK_EVALS 17       /* a b c d a_next b_next d_next sigma_1 sigma_2 sigma_3 q_arith q_c q_l q_r z_next t r */
 #define PM_PLONK_CHALLENGES 10  /* beta gamma alpha range_sep logic_sep fixed_sep var_sep z aw aw_shifted */
 #define PM_PLONK_PROOF_BYTES 1040
-/* prove flag: also absorb the public inputs (count, then position and value of each) before round 1.
- * dusk-plonk 0.8.2 does not (its transcript never sees them); without it the statement is not bound to the
- * challenges.  Off = byte-compatible with the restated upstream transcript. */
+/* prove flags.  DEFAULT (flags = 0): the public inputs (count, then position and value of every DECLARED input --
+ * pass the positions of zero-valued inputs too) are absorbed into the transcript before round 1, so the statement is
+ * bound to every challenge.  dusk-plonk 0.8.2 does not do that (its transcript never sees the public inputs):
+ * PM_PLONK_UPSTREAM_TRANSCRIPT reproduces the restated upstream message sequence byte for byte and is what a drop-in
+ * for dusk's Prover must pass ("Transcript modes").  The two modes agree up to and including the
+ * four wire commitments and differ from `beta` on.  PM_PLONK_BIND_PUBLIC_INPUTS (r01/r02 spelling of the default) is
+ * accepted and ignored. */
 #define PM_PLONK_BIND_PUBLIC_INPUTS 1u
+#define PM_PLONK_UPSTREAM_TRANSCRIPT 2u
 typedef struct pm_prover_key pm_prover_key;
 typedef struct pm_plonk_proof {
   uint64_t commitments[11][12];                  /* a b c d z t_1 t_2 t_3 t_4 w_z w_zw, affine, (0, 0) = identity */

@@ -283,7 +283,7 @@ class ProverKey {
     }
     pm_plonk_proof raw;
     ctx_->check(pm_plonk_prove(ctx_->get(), key_, ck.bases(), witness.data(), pos.data(), val.data(), pos.size(),
-                               bind_public_inputs ? PM_PLONK_BIND_PUBLIC_INPUTS : 0u, &raw));
+                               bind_public_inputs ? 0u : PM_PLONK_UPSTREAM_TRANSCRIPT, &raw));
     Proof p;
     for (int i = 0; i < 11; ++i) std::copy(raw.commitments[i], raw.commitments[i] + 12, p.commitments[i].begin());
     for (int i = 0; i < PM_PLONK_EVALS; ++i) std::copy(raw.evaluations[i], raw.evaluations[i] + 4, p.evaluations[i].begin());

@@ -41,7 +41,7 @@ class PlonkProof(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint32)
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 VK_POINTS = (C.c_uint64 * 12) * 15
-PLONK_SELECTORS, PLONK_PROOF_BYTES, PLONK_BIND_PUBLIC_INPUTS = 11, 1040, 1
+PLONK_SELECTORS, PLONK_PROOF_BYTES, PLONK_BIND_PUBLIC_INPUTS, PLONK_UPSTREAM_TRANSCRIPT = 11, 1040, 1, 2
 COMM_ID_BYTES, COMM_MAX_POINTS = 128, 16
 LINCOMB_MAX = 16
 

@@ -27,19 +27,31 @@ int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   return PM_OK;
 }
 
-int order_on(pm_ctx* ctx, StreamOrder& o, hipStream_t st) {
+static int order_enter(pm_ctx* ctx, StreamOrder& o, hipStream_t st) {
+  if (!o.ev) PM_HIP(ctx, hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
   if (o.used && o.last != st) {
-    if (!o.ev) PM_HIP(ctx, hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
-    if (hipEventRecord(o.ev, o.last) == hipSuccess) {
-      PM_HIP(ctx, hipStreamWaitEvent(st, o.ev, 0));
-    } else {   // the caller destroyed its previous stream: everything on it has been submitted, wait for the device
-      (void)hipGetLastError();
-      PM_HIP(ctx, hipDeviceSynchronize());
+    if (o.pending) {   // the predecessor ran on the context's own stream: record now (that stream is ours, always valid)
+      PM_HIP(ctx, hipEventRecord(o.ev, ctx->stream));
+      o.pending = false;
     }
+    PM_HIP(ctx, hipStreamWaitEvent(st, o.ev, 0));
+  }
+  return PM_OK;
+}
+OrderScope::OrderScope(pm_ctx* c, StreamOrder& ord, hipStream_t s) : ctx(c), o(ord), st(s), rc(order_enter(c, ord, s)) {}
+OrderScope::~OrderScope() {
+  // whatever this call enqueued (also on an error path) is what a successor on another stream has to wait for.  A
+  // caller's stream is never touched again after the call returns: its event is recorded here.
+  if (st == ctx->stream) {
+    o.pending = true;
+  } else if (o.ev && hipEventRecord(o.ev, st) == hipSuccess) {
+    o.pending = false;
+  } else {
+    (void)hipGetLastError();
+    return;
   }
   o.last = st;
   o.used = true;
-  return PM_OK;
 }
 
 static hipEvent_t prof_event(pm_ctx* ctx) {

@@ -8,6 +8,7 @@
 // on machines without it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the entry points are bound with dlsym, nothing links against librccl
 
 #include <cstring>
 #include <vector>
@@ -16,21 +17,21 @@
 
 namespace pm {
 
-// the handful of RCCL entry points used (rccl.h: ncclResult_t = int, ncclComm_t = opaque pointer)
-struct ncclUniqueIdRaw {
-  char internal[PM_COMM_ID_BYTES];
-};
+// the handful of RCCL entry points used, with the prototypes of the installed rccl.h (the hand-written
+// ones of r02 could only have failed on a multi-GPU node)
+static_assert(sizeof(ncclUniqueId) == PM_COMM_ID_BYTES, "PM_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+typedef ncclUniqueId ncclUniqueIdRaw;
 struct Rccl {
   void* lib = nullptr;
-  int (*GetUniqueId)(ncclUniqueIdRaw*) = nullptr;
-  int (*CommInitRank)(void**, int, ncclUniqueIdRaw, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int /* ncclDataType_t */, void*, hipStream_t) = nullptr;
-  int (*Send)(const void*, size_t, int, int /* peer */, void*, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int /* peer */, void*, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
   bool p2p() const { return Send && Recv && GroupStart && GroupEnd; }
 };
@@ -55,8 +56,8 @@ static Rccl& rccl() {
   });
   return r;
 }
-static const int kNcclUint8 = 1;
-static const int kNcclUint64 = 5;   // ncclUint64 (nccl.h / rccl.h: int8 0, uint8 1, int32 2, uint32 3, int64 4, uint64 5)
+static const ncclDataType_t kNcclUint8 = ncclUint8;
+static const ncclDataType_t kNcclUint64 = ncclUint64;
 
 // message of one rank: [count | PM_COMM_MAX_POINTS x 18 limbs]; count = 0 is the abort marker of a rank
 // whose local work failed (it still enters the collective, so no peer blocks)
@@ -83,14 +84,15 @@ int comm_alltoall(pm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_pe
   if (!ctx->comm) return set_err(ctx, PM_ERR_EXCHANGE, "no communicator: pm_comm_init first");
   Rccl& r = rccl();
   if (!r.p2p()) return set_err(ctx, PM_ERR_EXCHANGE, "librccl has no ncclSend / ncclRecv");
-  int nrc = r.GroupStart();
-  for (int p = 0; p < ctx->comm_world && nrc == 0; ++p) {
-    nrc = r.Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclUint8, p, ctx->comm, st);
-    if (nrc == 0) nrc = r.Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclUint8, p, ctx->comm, st);
+  ncclComm_t comm = (ncclComm_t)ctx->comm;
+  ncclResult_t nrc = r.GroupStart();
+  for (int p = 0; p < ctx->comm_world && nrc == ncclSuccess; ++p) {
+    nrc = r.Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclUint8, p, comm, st);
+    if (nrc == ncclSuccess) nrc = r.Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclUint8, p, comm, st);
   }
-  const int erc = r.GroupEnd();
-  if (nrc == 0) nrc = erc;
-  if (nrc != 0) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclSend/ncclRecv: ") + r.GetErrorString(nrc));
+  const ncclResult_t erc = r.GroupEnd();
+  if (nrc == ncclSuccess) nrc = erc;
+  if (nrc != ncclSuccess) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclSend/ncclRecv: ") + r.GetErrorString(nrc));
   return PM_OK;
 }
 
@@ -103,7 +105,7 @@ extern "C" int pm_comm_unique_id(uint8_t id[PM_COMM_ID_BYTES]) {
   Rccl& r = rccl();
   if (!r.ok()) return PM_ERR_EXCHANGE;
   ncclUniqueIdRaw raw;
-  if (r.GetUniqueId(&raw) != 0) return PM_ERR_EXCHANGE;
+  if (r.GetUniqueId(&raw) != ncclSuccess) return PM_ERR_EXCHANGE;
   memcpy(id, raw.internal, PM_COMM_ID_BYTES);
   return PM_OK;
 }
@@ -117,9 +119,9 @@ extern "C" int pm_comm_init(pm_ctx* ctx, const uint8_t id[PM_COMM_ID_BYTES], int
   PM_HIP(ctx, hipSetDevice(ctx->device));
   ncclUniqueIdRaw raw;
   memcpy(raw.internal, id, PM_COMM_ID_BYTES);
-  void* comm = nullptr;
-  const int nrc = r.CommInitRank(&comm, world, raw, rank);
-  if (nrc != 0) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclCommInitRank: ") + r.GetErrorString(nrc));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t nrc = r.CommInitRank(&comm, world, raw, rank);
+  if (nrc != ncclSuccess) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclCommInitRank: ") + r.GetErrorString(nrc));
   hipError_t e = hipMalloc(&ctx->comm_send, MSG_WORDS * 8);
   if (e == hipSuccess) e = hipMalloc(&ctx->comm_recv, MSG_WORDS * 8 * (size_t)world);
   if (e == hipSuccess) e = hipHostMalloc(&ctx->comm_host, MSG_WORDS * 8 * ((size_t)world + 1), hipHostMallocDefault);
@@ -142,7 +144,7 @@ extern "C" int pm_comm_destroy(pm_ctx* ctx) {
   if (!ctx->comm) return PM_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)rccl().CommDestroy(ctx->comm);
+  (void)rccl().CommDestroy((ncclComm_t)ctx->comm);
   (void)hipFree(ctx->comm_send);
   (void)hipFree(ctx->comm_recv);
   (void)hipHostFree(ctx->comm_host);
@@ -173,11 +175,18 @@ extern "C" int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k) {
   h_send[0] = k;
   if (k) memcpy(h_send + 1, xyz, 144 * (size_t)k);
   hipStream_t st = ctx->stream;
-  PM_HIP(ctx, hipMemcpyAsync(ctx->comm_send, h_send, MSG_WORDS * 8, hipMemcpyHostToDevice, st));
-  const int nrc = r.AllGather(ctx->comm_send, ctx->comm_recv, MSG_WORDS, kNcclUint64, ctx->comm, st);
-  if (nrc != 0) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclAllGather: ") + r.GetErrorString(nrc));
+  // a rank that cannot stage its message still enters the collective -- with the abort marker (count 0), written by a
+  // memset if the copy failed -- so that no peer waits in ncclAllGather for ever (it has no timeout)
+  bool staged = hipMemcpyAsync(ctx->comm_send, h_send, MSG_WORDS * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (!staged) {
+    (void)hipGetLastError();
+    (void)hipMemsetAsync(ctx->comm_send, 0, 8, st);
+  }
+  const ncclResult_t nrc = r.AllGather(ctx->comm_send, ctx->comm_recv, MSG_WORDS, kNcclUint64, (ncclComm_t)ctx->comm, st);
+  if (nrc != ncclSuccess) return set_err(ctx, PM_ERR_EXCHANGE, std::string("ncclAllGather: ") + r.GetErrorString(nrc));
   PM_HIP(ctx, hipMemcpyAsync(h_recv, ctx->comm_recv, MSG_WORDS * 8 * (size_t)world, hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
+  if (!staged) return set_err(ctx, PM_ERR_EXCHANGE, "staging the exchange message failed: this rank aborted the exchange");
   if (k == 0) return set_err(ctx, PM_ERR_EXCHANGE, "this rank aborted the exchange");
   const int rc = fold_gathered(h_recv, world, k, xyz);
   if (rc == PM_ERR_EXCHANGE) return set_err(ctx, rc, "a peer rank aborted the exchange (or sent a different count)");

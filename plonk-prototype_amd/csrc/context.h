@@ -17,14 +17,20 @@ struct DeviceBuffer {
 };
 
 // A group of shared resources (scratch buffers, lazily built tables) that calls on different HIP
-// streams would otherwise race on.  Every call that touches the group goes through order_on():
-// when the stream differs from the one that used the group last, the new stream first waits for
-// an event recorded on the old one, so a context behaves like one in-order queue per group even
-// when its *_dev entry points are driven from several streams.  Groups are independent: an NTT on
-// one stream and an MSM on another still overlap.
+// streams would otherwise race on.  Every call that touches the group holds an OrderScope: on entry,
+// when the stream differs from the one that used the group last, the new stream first waits for the
+// event the PREVIOUS call recorded on its own stream when it ended; on exit the call records that
+// event for its successor.  The library never touches a stream after the call it was passed to
+// returned (a caller may destroy it), and only the library's own work is ordered.  A context behaves
+// like one in-order queue per group even when its *_dev entry points are driven from several
+// streams; groups are independent: an NTT on one stream and an MSM on another still overlap.
+// Calls on the context's OWN stream (what a caller gets by passing no stream; the library creates and destroys it)
+// record lazily -- when a call on another stream next needs the event -- because an event record per call is +2 % on
+// a forward + inverse 2^20 NTT (profiles/r03_order_scope_ab.txt).
 struct StreamOrder {
   hipStream_t last = nullptr;
-  bool used = false;
+  bool used = false;      // an earlier call used the group
+  bool pending = false;   // ... on the context's own stream, and its closing event is not recorded yet
   hipEvent_t ev = nullptr;
 };
 
@@ -118,7 +124,16 @@ struct ProfScope {
 int prof_collect(pm_ctx* ctx);
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
 int comm_alltoall(pm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer, hipStream_t st);   // comm.hip
-int order_on(pm_ctx* ctx, StreamOrder& o, hipStream_t st);
+struct OrderScope {
+  pm_ctx* ctx;
+  StreamOrder& o;
+  hipStream_t st;
+  int rc;
+  OrderScope(pm_ctx* c, StreamOrder& ord, hipStream_t s);
+  ~OrderScope();
+  OrderScope(const OrderScope&) = delete;
+  OrderScope& operator=(const OrderScope&) = delete;
+};
 
 #define PM_HIP(ctx, call)                                                                   \
   do {                                                                                      \

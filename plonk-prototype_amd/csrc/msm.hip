@@ -598,10 +598,8 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
   if (bases->table_c && (size_t)bases->n * ((256 + bases->table_c - 1) / bases->table_c) > 0x7fffffffu)
     return set_err(ctx, PM_ERR_BAD_ARG, "window table too large for 31-bit point indices");
-  {
-    int orc = order_on(ctx, ctx->ord_msm, st);   // msm_ws and the pinned result buffer are shared by all streams
-    if (orc) return orc;
-  }
+  OrderScope order_scope(ctx, ctx->ord_msm, st);   // msm_ws and the pinned result buffer are shared by all streams
+  if (order_scope.rc) return order_scope.rc;
   MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
   if (g.bins > SORT_MAX_BINS || g.rbits > SORT_MAX_RBITS || g.ts == 0)
     return set_err(ctx, PM_ERR_BAD_ARG, "window width outside what the bucket fill is laid out for");
@@ -962,8 +960,10 @@ extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t win
   // with n -- 2^17 points (an 8-way shard of 2^20): c = 16, 1.4 ms; 2^20: c = 20, 4.1 ms; 2^21: c = 20,
   // 6.8 ms.  Only widths whose top window still spans several bits are used (13 -> 8 bits, 16 -> 15,
   // 20 -> 15): a top window of 1-4 bits (c = 17, 18, 21) puts n / 8 points into each of a few buckets.
-  const u32 c = window_bits ? window_bits : (lg <= 15 ? 13u : (lg <= 18 ? 16u : 20u));
-  if (c < 8 || c > 22) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..22");
+  // 2^24 (profiles/r03_msm_sweep.txt): c = 22 -- 12 table rows instead of 13, 2^21 buckets -- 36.6 ms against 38.9 ms
+  // for c = 20 and 37.7 ms for c = 24 (whose 2^23 buckets cost 4.3 ms to reduce).
+  const u32 c = window_bits ? window_bits : (lg <= 15 ? 13u : (lg <= 18 ? 16u : (lg <= 22 ? 20u : 22u)));
+  if (c < 8 || c > 24) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..24");
   if (n == 0) return PM_OK;
   const u32 nwin = (256 + c - 1) / c;
   if (n * nwin > 0x7fffffffu) return set_err(ctx, PM_ERR_LENGTH, "n * windows exceeds 2^31 table entries");

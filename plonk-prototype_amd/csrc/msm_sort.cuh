@@ -46,7 +46,7 @@ static constexpr u32 SORT_THREADS0 = SORT_T0;    // histogram kernel (a tile is 
 static constexpr u32 SORT_TILE1_PAIRS = 14 * SORT_THREADS1;   // scatter kernel: pairs staged per tile (8 B each in LDS)
 static constexpr u32 SORT_IPT = 16;              // local sort: pairs per thread and tile
 static constexpr u32 SORT_TILE2_PAIRS = SORT_THREADS * SORT_IPT;
-static constexpr u32 SORT_MAX_BINS = 2048;       // partitions one MSM of a batch may have (LDS histogram of a tile)
+static constexpr u32 SORT_MAX_BINS = 4096;       // partitions one MSM of a batch may have (LDS histogram of a tile)
 static constexpr u32 SORT_MAX_RBITS = 12;        // local bins: 2^R counters + 2^R cursors in LDS
 
 struct MsmGeom {

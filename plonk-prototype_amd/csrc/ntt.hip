@@ -270,10 +270,8 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     return set_err(ctx, PM_ERR_BAD_ARG, "batch strides shorter than the vectors");
   if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET)) return set_err(ctx, PM_ERR_BAD_ARG, "unknown flags");
   PM_HIP(ctx, hipSetDevice(ctx->device));
-  {
-    int orc = order_on(ctx, ctx->ord_ntt, st);   // scratch vectors and lazily built tables are shared by all streams
-    if (orc) return orc;
-  }
+  OrderScope order_scope(ctx, ctx->ord_ntt, st);   // scratch vectors and lazily built tables are shared by all streams
+  if (order_scope.rc) return order_scope.rc;
   const int dir = (flags & PM_NTT_INVERSE) ? 1 : 0;
   const bool coset = (flags & PM_NTT_COSET) != 0;
 
@@ -425,8 +423,8 @@ extern "C" int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n) {
     return set_err(ctx, PM_ERR_DOMAIN_TOO_LARGE, "log_n >= 32 (Fr two-adicity)");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   if (log_n == 0) return PM_OK;
-  int orc = order_on(ctx, ctx->ord_ntt, ctx->stream);
-  if (orc) return orc;
+  OrderScope order_scope(ctx, ctx->ord_ntt, ctx->stream);
+  if (order_scope.rc) return order_scope.rc;
   // exactly the tables ntt_run() would build on the first transform of this size: domain and coset
   // tables, the step tables of the kernels the plan picks (radix-4 or radix-8 family), and the
   // inter-pass twiddle tables of both directions
@@ -661,13 +659,25 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
   u32x4* recv = world == 1 ? send : send + 2 * blk;
   hipStream_t st;
   NttDomainTables* dt = nullptr;
+  // the transform holds the NTT resource group from here to its last launch, with the context unlocked in between (the
+  // exchange callback): the scope's closing event is recorded, under the lock, when the function returns
+  struct HeldOrder {
+    pm_ctx* ctx;
+    OrderScope* s;
+    ~HeldOrder() {
+      if (!s) return;
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      delete s;
+    }
+  } held{ctx, nullptr};
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     PM_HIP(ctx, hipSetDevice(ctx->device));
     st = ctx->stream;
     if (world > 1 && !exchange && (!ctx->comm || ctx->comm_world != (int)world || ctx->comm_rank != (int)rank))
       return set_err(ctx, PM_ERR_EXCHANGE, "no exchange callback and no matching communicator (pm_comm_init)");
-    int rc = order_on(ctx, ctx->ord_ntt, st);
+    held.s = new OrderScope(ctx, ctx->ord_ntt, st);
+    int rc = held.s->rc;
     if (!rc) rc = get_domain_tables(ctx, inverse ? 1 : 0, log_n, coset, &dt, st);
     if (rc) return rc;
   }

@@ -578,7 +578,8 @@ extern "C" int pm_fr_poly_evaluate_many_dev(pm_ctx* ctx, uint32_t k, const void*
   }
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  int rc = order_on(ctx, ctx->ord_poly, st);
+  OrderScope order_scope(ctx, ctx->ord_poly, st);
+  int rc = order_scope.rc;
   if (rc) return rc;
   const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
   const size_t seg = (size_t)256 * L;
@@ -650,7 +651,8 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   size_t tot_entries = 0;
   for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
   if (sz.size() == 1) tot_entries = (m + SC_K - 1) / SC_K;       // a small input still goes totals -> base -> replay
-  int rc = order_on(ctx, ctx->ord_poly, st);
+  OrderScope order_scope(ctx, ctx->ord_poly, st);
+  int rc = order_scope.rc;
   if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, tot_entries * 48 + 64);
   if (rc) return rc;
   if (sz.size() == 1) sz.push_back((m + SC_K - 1) / SC_K);
@@ -714,7 +716,8 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   if (sz.size() == 1) sz.push_back((n + SC_K - 1) / SC_K);
   size_t tot_entries = 0;
   for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
-  int rc = order_on(ctx, ctx->ord_poly, st);
+  OrderScope order_scope(ctx, ctx->ord_poly, st);
+  int rc = order_scope.rc;
   if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, tot_entries * 48 + 64);
   if (rc) return rc;
   std::vector<u32x4*> lvl(sz.size());
@@ -770,7 +773,8 @@ extern "C" int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, voi
   const unsigned blocks = (unsigned)((want_threads + 255) / 256);
   const size_t T = (size_t)blocks * 256;
   const u32 L = (u32)((n + T - 1) / T);
-  int rc = order_on(ctx, ctx->ord_poly, st);
+  OrderScope order_scope(ctx, ctx->ord_poly, st);
+  int rc = order_scope.rc;
   if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, n * 48);
   if (rc) return rc;
   ProfScope prof(ctx, st, "fr_batch_inverse");

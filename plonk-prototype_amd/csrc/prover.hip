@@ -404,7 +404,24 @@ struct Shard {
   bool on = false;             // the SRS is split: partial sums are exchanged
   pm_exchange_fn fn = nullptr; // nullptr with on = true: the context's RCCL communicator (pm_g1_allgather_fold)
   void* user = nullptr;
+  mutable bool aborted = false;   // an exchange of this call already carried / returned the abort marker
 };
+// One exchange of k partial points (k = 0: the abort marker).
+static int shard_exchange(pm_ctx* ctx, const Shard& sh, u64* xyz, uint32_t k) {
+  const int rc = sh.fn ? (sh.fn(sh.user, xyz, k) != 0 ? PM_ERR_EXCHANGE : PM_OK) : pm_g1_allgather_fold(ctx, xyz, k);
+  if (k == 0 || rc != PM_OK) sh.aborted = true;
+  return k == 0 && rc == PM_OK ? PM_ERR_EXCHANGE : rc;
+}
+// A sharded call that fails anywhere OUTSIDE an exchange -- an NTT, the quotient, an allocation, an argument that is
+// wrong on this rank only -- must still meet its peers in their next collective, or they block in it for ever
+// (ncclAllGather has no timeout): one abort marker, after which every rank returns an error.
+static int shard_leave(pm_ctx* ctx, const Shard& sh, int rc) {
+  if (rc != PM_OK && sh.on && ctx && !sh.aborted) {
+    u64 xyz[18] = {0};
+    (void)shard_exchange(ctx, sh, xyz, 0);
+  }
+  return rc;
+}
 static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const void* d, size_t n, size_t stride,
                         uint32_t batch, u64 (*out_xy)[12]) {
   u64 xyz[16 * 18];
@@ -421,19 +438,82 @@ static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const 
   }
   if (sh.on) {
     // k = 0 tells the peers that this rank gave up: they get an error back and stop too
-    const uint32_t k = rc == PM_OK ? batch : 0;
-    const int xrc = sh.fn ? (sh.fn(sh.user, xyz, k) != 0 ? PM_ERR_EXCHANGE : PM_OK) : pm_g1_allgather_fold(ctx, xyz, k);
+    const int xrc = shard_exchange(ctx, sh, xyz, rc == PM_OK ? batch : 0);
     if (rc == PM_OK && xrc != PM_OK) rc = xrc;
   }
   if (rc) return rc;
   return pm_g1_to_affine_batch(xyz, batch, &out_xy[0][0], nullptr);   // one host inversion per batch
 }
 
+// The ranks' SRS slices must tile [0, n): a gap or an overlap would give a well-formed but wrong commitment that no
+// rank can see.  One extra exchange per key: every rank contributes len * G and (sum of its coefficient indices) * G
+// (G the group generator, small host-side scalar multiplications); the sums must be n * G and n (n - 1) / 2 * G.
+static pm::host::XYZZ host_mul_generator(u64 k) {
+  using namespace pm::host;
+  // the BLS12-381 G1 generator, canonical limbs -> Montgomery
+  static const u64 GX[6] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL,
+                            0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL};
+  static const u64 GY[6] = {0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL,
+                            0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
+  const Field<6>& F = FP();
+  HFp r2, x, y;
+  memcpy(r2.l, F.r2, 48);
+  memcpy(x.l, GX, 48);
+  memcpy(y.l, GY, 48);
+  XYZZ g;
+  g.x = mul(x, r2, F);
+  g.y = mul(y, r2, F);
+  g.zz = one(F);
+  g.zzz = one(F);
+  XYZZ acc = xyzz_identity();
+  for (int bit = 63; bit >= 0; --bit) {
+    acc = xyzz_double(acc);
+    if ((k >> bit) & 1) acc = xyzz_add(acc, g);
+  }
+  return acc;
+}
+static void host_to_projective(const pm::host::XYZZ& p, u64 out[18]) {
+  pm::host::HFp x, y;
+  memset(out, 0, 144);
+  if (!pm::host::xyzz_to_affine(p, x, y)) {
+    memcpy(out + 6, pm::host::FP().one, 48);   // (0, 1, 0)
+    return;
+  }
+  memcpy(out, x.l, 48);
+  memcpy(out + 6, y.l, 48);
+  memcpy(out + 12, pm::host::FP().one, 48);
+}
+static int check_slice_cover(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, size_t n) {
+  const size_t have = pm_g1_bases_len(ck);
+  const u64 cnt = sh.lo < n ? std::min<size_t>(have, n - sh.lo) : 0;
+  const u64 idx_sum = cnt * (u64)sh.lo + (cnt ? cnt * (cnt - 1) / 2 : 0);
+  u64 xyz[2 * 18], want[2 * 18], got_xy[2 * 12], want_xy[2 * 12];
+  host_to_projective(host_mul_generator(cnt), xyz);
+  host_to_projective(host_mul_generator(idx_sum), xyz + 18);
+  host_to_projective(host_mul_generator((u64)n), want);
+  host_to_projective(host_mul_generator((u64)n * (n - 1) / 2), want + 18);
+  PK_TRY(shard_exchange(ctx, sh, xyz, 2));
+  PK_TRY(pm_g1_to_affine_batch(xyz, 2, got_xy, nullptr));
+  PK_TRY(pm_g1_to_affine_batch(want, 2, want_xy, nullptr));
+  if (memcmp(got_xy, want_xy, sizeof got_xy) != 0) {
+    ctx->err = "the ranks' commit-key slices do not tile [0, n): a gap or an overlap";
+    return PM_ERR_LENGTH;
+  }
+  return PM_OK;
+}
+
+static int key_commit_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard,
+                           const char* transcript_label, uint64_t (*vk_out)[12]);
 static int key_commit_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard,
+                           const char* transcript_label, uint64_t (*vk_out)[12]) {
+  return shard_leave(ctx, shard, key_commit_body(ctx, pk, ck, shard, transcript_label, vk_out));
+}
+static int key_commit_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard,
                            const char* transcript_label, uint64_t (*vk_out)[12]) {
   if (!ctx || !pk || !ck) return PM_ERR_BAD_ARG;
   const size_t n = pk->n;
   if (!shard.on && pm_g1_bases_len(ck) < n) return PM_ERR_LENGTH;
+  if (shard.on) PK_TRY(check_slice_cover(ctx, ck, shard, n));
   // the verifier key: commitments to the 11 selector and the 4 sigma polynomials
   PK_TRY(commit_batch(ctx, ck, shard, pk->sel_coeffs, n, n, NSEL, &pk->vk[0]));
   PK_TRY(commit_batch(ctx, ck, shard, pk->sigma_coeffs, n, n, 4, &pk->vk[NSEL]));
@@ -504,9 +584,14 @@ static int scatter_public_inputs(pm_ctx* ctx, pm_prover_key* pk, const uint64_t*
   return PM_OK;
 }
 
-static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
+static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
                       const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
                       pm_plonk_proof* out);
+static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
+                      const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
+                      pm_plonk_proof* out) {
+  return shard_leave(ctx, shard, prove_body(ctx, pk, ck, shard, d_witness, pi_positions, pi_values, n_pi, flags, out));
+}
 
 extern "C" int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck_slice, size_t first_coefficient,
                                       const void* d_witness, const uint64_t* pi_positions, const uint64_t* pi_values,
@@ -537,12 +622,12 @@ struct BusyGuard {   // one proof at a time per key: the key owns the per-proof 
 };
 }  // namespace
 
-static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
+static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
                       const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
                       pm_plonk_proof* out) {
   if (!ctx || !pk || !ck || !d_witness || !out) return PM_ERR_BAD_ARG;
   if (n_pi && (!pi_positions || !pi_values)) return PM_ERR_BAD_ARG;
-  if (flags & ~PM_PLONK_BIND_PUBLIC_INPUTS) return PM_ERR_BAD_ARG;
+  if (flags & ~(PM_PLONK_BIND_PUBLIC_INPUTS | PM_PLONK_UPSTREAM_TRANSCRIPT)) return PM_ERR_BAD_ARG;
   if (!pk->committed) return PM_ERR_BAD_ARG;   // pm_plonk_key_commit first: the transcript starts from the verifier key
   BusyGuard guard(pk);
   if (!guard.ok) return PM_ERR_BUSY;
@@ -552,9 +637,9 @@ static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   for (size_t i = 0; i < n_pi; ++i)
     if (pi_positions[i] >= n) return PM_ERR_LENGTH;
   Transcript ts = pk->base;
-  if (flags & PM_PLONK_BIND_PUBLIC_INPUTS) {
-    // not in dusk-plonk 0.8.2 (its transcript never sees the public inputs): binds the statement to the
-    // challenges so that it cannot be chosen after them
+  if (!(flags & PM_PLONK_UPSTREAM_TRANSCRIPT)) {
+    // the default; not in dusk-plonk 0.8.2 (its transcript never sees the public inputs): binds the statement to
+    // the challenges so that it cannot be chosen after them
     ts.append_u64("pi_len", n_pi);
     for (size_t i = 0; i < n_pi; ++i) {
       ts.append_u64("pi_pos", pi_positions[i]);

@@ -229,7 +229,7 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, bind_public
             public_inputs = public_inputs.to_host()
         pos, val = sparse_public_inputs(public_inputs)
     raw = _lib.PlonkProof()
-    flags = _lib.PLONK_BIND_PUBLIC_INPUTS if bind_public_inputs else 0
+    flags = 0 if bind_public_inputs else _lib.PLONK_UPSTREAM_TRANSCRIPT   # binding is the library's default
     p_pos = pos.ctypes.data_as(_lib.u64p) if pos.size else None
     p_val = val.ctypes.data_as(_lib.u64p) if pos.size else None
     try:

@@ -82,6 +82,69 @@ def test_sharded_prover_world2_equals_single_gpu(ctx):
         assert blob == single, rank
 
 
+def _failing_worker(rank, world, port, q, mode):
+    """mode "pi": rank 1 passes a public-input position outside the circuit (an argument error on ONE rank, far from
+    any MSM); mode "gap": rank 1's slice starts one coefficient late.  No rank may block: both must get an error."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd.dist import ShardedCommitKey, shard_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        circuit, wit, pi, srs = _inputs()
+        ctx = pa.Context(0)
+        lo, hi = shard_range(N, rank, world)
+        codes = []
+        if mode == "gap":
+            shift = 1 if rank == 1 else 0
+            ck = ShardedCommitKey(srs[lo + shift:hi], lo + shift, N, ctx)
+            try:
+                pa.preprocess(circuit, ctx, ck)
+                codes.append(0)
+            except pa.Error as e:
+                codes.append(e.code)
+        else:
+            ck = ShardedCommitKey(srs[lo:hi], lo, N, ctx)
+            pk = pa.preprocess(circuit, ctx, ck)
+            pos, val = pa.prover.sparse_public_inputs(pi)
+            bad = pos.copy()
+            if rank == 1:
+                bad[0] = N + 5
+            try:
+                pa.prove(pk, ck, wit, (bad, val))
+                codes.append(0)
+            except pa.Error as e:
+                codes.append(e.code)
+            # the key is usable again afterwards: both ranks prove normally
+            codes.append(len(pa.prove(pk, ck, wit, pi).to_bytes()))
+        q.put((rank, codes))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["pi", "gap"])
+def test_one_rank_failing_outside_an_msm_does_not_block_its_peer(mode):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_failing_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if mode == "gap":
+        assert res[0] == [-6] and res[1] == [-6]            # PM_ERR_LENGTH on every rank: the slices do not tile [0, n)
+    else:
+        assert res[1][0] == -6 and res[0][0] == -7          # the bad rank: PM_ERR_LENGTH; its peer: PM_ERR_EXCHANGE
+        assert res[0][1] == 1040 and res[1][1] == 1040
+
+
 def test_library_communicator_world1(ctx, oracle):
     """The in-library RCCL exchange on the one GPU of the test box (a one-rank communicator: two RCCL ranks
     cannot share a device): unique id, ncclCommInitRank, ncclAllGather through pm_g1_allgather_fold, and the

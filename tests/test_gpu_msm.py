@@ -121,7 +121,7 @@ def test_commit_key_mirror(ctx, oracle):
         pa.msm_variable_base(pts, poly, ctx)                           # length mismatch
 
 
-@pytest.mark.parametrize("c", [0, 8, 13, 16])
+@pytest.mark.parametrize("c", [0, 8, 13, 16, 20, 22, 24])
 def test_precomputed_window_table(ctx, oracle, c):
     """pm_g1_bases_precompute: same result from the one-bucket-set path, for every table width,
     for prefixes of the SRS (commit of a shorter polynomial) and for offset shards."""
@@ -141,6 +141,11 @@ def test_precomputed_window_table(ctx, oracle, c):
     assert np.array_equal(pa.g1_to_affine(part)[0], oracle.g1_msm(pts[1000:4000], sc[1000:4000], SCALAR_MONTGOMERY, 8))
     with pytest.raises(pa.Error):
         bases.precompute(c)                                           # only once
+    # a second MSM of another size on the same context right away: the bucket fill's control block is shared
+    got, _ = pa.g1_to_affine(pa.msm_variable_base(pts[:7], sc[:7], ctx))
+    assert np.array_equal(got, oracle.g1_msm(pts[:7], sc[:7], SCALAR_MONTGOMERY, 8))
+    got, _ = pa.g1_to_affine(bases.msm(sc[:4097]))
+    assert np.array_equal(got, oracle.g1_msm(pts[:4097], sc[:4097], SCALAR_MONTGOMERY, 8))
     # skewed digits through the table path
     eq = np.repeat(oracle.fr_sample(7, 1), n, axis=0)
     assert np.array_equal(pa.g1_to_affine(bases.msm(eq))[0], oracle.g1_msm(pts, eq, SCALAR_MONTGOMERY, 8))

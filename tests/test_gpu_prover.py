@@ -279,6 +279,42 @@ def test_prove_is_deterministic_and_transcript_bound(ctx, oracle):
     assert ch["aw_shifted"] == p6.challenges["aw_shifted"]
 
 
+def test_transcript_modes(ctx, oracle):
+    """PM_PLONK_UPSTREAM_TRANSCRIPT (dusk-plonk 0.8.2: public inputs not absorbed) against the library's default
+    (absorbed before round 1): same round-1 commitments, every challenge from beta on differs, and each mode equals
+    the verifier-side replay of its own message sequence -- including a DECLARED public input whose value is zero."""
+    import plonk_prototype_amd.prover as PR
+    n = 64
+    circuit, wit, pi, srs, ck, pk, _ = _setup(ctx, oracle, n, seed=12)
+    hard, up = PR.prove(pk, ck, wit, pi), PR.prove(pk, ck, wit, pi, bind_public_inputs=False)
+    for w in "abcd":
+        assert np.array_equal(hard.commitments[w], up.commitments[w])             # no challenge before round 2
+    for name in ("beta", "gamma", "alpha", "range_sep", "logic_sep", "fixed_sep", "var_sep", "z", "aw", "aw_shifted"):
+        assert hard.challenges[name] != up.challenges[name], name
+    assert not np.array_equal(hard.commitments["z"], up.commitments["z"])
+    for proof, bind in ((hard, True), (up, False)):
+        ch = PR.derive_challenges(proof, pk.verifier_key, n, pi, bind_public_inputs=bind)
+        assert all(ch[k] == v for k, v in proof.challenges.items()), bind
+    # the flag of the r01 / r02 header is still accepted and means the default
+    pos, val = PR.sparse_public_inputs(pi)
+    raw = PR._lib.PlonkProof()
+    import ctypes as C
+    d_wit = PR.DeviceVector.from_host(ctx, np.ascontiguousarray(wit, dtype=np.uint64).reshape(4 * n, 4))
+    ctx._check(ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, pos.ctypes.data_as(PR._lib.u64p),
+                                       val.ctypes.data_as(PR._lib.u64p), pos.size, PR._lib.PLONK_BIND_PUBLIC_INPUTS, C.byref(raw)))
+    assert PR.fr_from_limbs(np.array(raw.challenges[0], dtype=np.uint64)) == hard.challenges["beta"]
+    assert ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, None, None, 0, 8, C.byref(raw)) == -1   # unknown flag
+    d_wit.free()
+    # a declared public input with value zero: its position is part of the statement
+    zpos = np.concatenate([pos, np.array([n - 2], np.uint64)])
+    zval = np.concatenate([val, np.zeros((1, 4), np.uint64)])
+    zp = PR.prove(pk, ck, wit, (zpos, zval))
+    assert zp.challenges["beta"] != hard.challenges["beta"]
+    assert np.array_equal(zp.commitments["a"], hard.commitments["a"])
+    assert PR.derive_challenges(zp, pk.verifier_key, n, (zpos, zval))["z"] == zp.challenges["z"]
+    assert PR.prove(pk, ck, wit, (zpos, zval), bind_public_inputs=False).to_bytes() == up.to_bytes()
+
+
 def test_several_public_inputs(ctx, oracle):
     """Public inputs on several rows (first, inner, last): the dense PI vector the library builds from the
     (position, value) pairs equals the one the oracle proves with, and each of them moves the challenges."""
@@ -547,10 +583,13 @@ def test_gpu_proof_passes_the_pairing_verifier(ctx, oracle, n, mixed):
         assert PV.verify(n, vk, comms, ev, ch, (pub_z + 1) % R, tau_g2)[1] is False
 
 
-@pytest.mark.parametrize("log_n,mixed", [(10, False), (10, True), (14, True)])
+@pytest.mark.parametrize("log_n,mixed", [(10, False), (10, True), (12, True), (14, True)])
 def test_prove_matches_the_c_prover(ctx, oracle, log_n, mixed):
     """Sizes beyond the big-int oracle: every commitment and evaluation of the GPU proof equals the
-    CPU prover composed from the C restatement (oracle/cpu_prover.py), same challenges."""
+    CPU prover composed from the C restatement (oracle/cpu_prover.py), same challenges -- and those challenges are
+    the ones the verifier's side of the transcript (a Python replay over the proof bytes) derives.  [12-True] is the
+    stand-in for BASELINE configs[0]: the domain size of the reference's smallest circuit
+    (ref:src/zk/circuits.rs:51-72, which does not compile as shipped: SURVEY F8) with every gate kind it emits."""
     import plonk_prototype_amd as pa
     import plonk_prototype_amd.prover as PR
     from oracle import cpu_prover as CP
@@ -561,6 +600,8 @@ def test_prove_matches_the_c_prover(ctx, oracle, log_n, mixed):
     pk = PR.preprocess(circuit, ctx, ck)
     proof = PR.prove(pk, ck, wit, pub)
     cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
+    replay = PR.derive_challenges(PR.Proof.from_bytes(proof.to_bytes()), pk.verifier_key, n, pub, t_eval=PR.fr_from_limbs(proof.evaluations["t"]))
+    assert all(replay[k] == v for k, v in proof.challenges.items())       # not only "the GPU's own challenges"
     exp = CP.prove(oracle, cpk, srs, wit, pub, proof.challenges, threads=8)
     assert set(exp["commitments"]) == set(proof.commitments) and set(exp["evaluations"]) == set(proof.evaluations)
     for k, v in exp["evaluations"].items():
