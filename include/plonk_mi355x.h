@@ -393,7 +393,8 @@ int pm_profile_enable(pm_ctx* ctx, int on);
 int pm_profile_select(pm_ctx* ctx, const char* kernel_name);
 int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap);
 /* Elementwise field kernels used by the parity tests: op 0 = Fr mul, 1 = Fr add, 2 = Fr sub,
- * 3 = Fp mul, 4 = Fp add, 5 = Fp sub.  Host pointers, n elements. */
+ * 3 = Fp mul, 4 = Fp add, 5 = Fp sub, 6 = Fr inverse of a, 7 = Fp inverse of a (b ignored; 0 -> 0).  Host pointers,
+ * n elements. */
 int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                      size_t n);
 

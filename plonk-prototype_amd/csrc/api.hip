@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "context.h"
+#include "field_inv.cuh"
 #include "fields.cuh"
 
 namespace pm {
@@ -101,6 +102,8 @@ __global__ void field_op_kernel(const u32x4* a, const u32x4* b, u32x4* out, size
   if (OP == 0) r = fe_abi_to_dev<P>(fe_mul<P>(x, y));
   if (OP == 1) r = fe_add<P>(x, y);
   if (OP == 2) r = fe_mul<P>(fe_sub<P, 2, 1>(x, y), fe_one<P>());
+  // 1 / x in the ABI form: the integer inverse of x R is x^-1 / R; times R^2 R' (and the product's 1 / R') = x^-1 R
+  if (OP == 3) r = fe_mul<P>(fe_inv_int<P>(x), fe_pow2<P, 64 * P::NS + P::W * P::N>());
   fe_store<P>(out + V * i, r);
 }
 
@@ -270,10 +273,10 @@ extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const ui
                                 uint64_t* out, size_t n) {
   if (!ctx || !a || !b || !out) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (op < 0 || op > 5) return set_err(ctx, PM_ERR_BAD_ARG, "op");
+  if (op < 0 || op > 7) return set_err(ctx, PM_ERR_BAD_ARG, "op");
   if (n == 0) return PM_OK;
   PM_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t esz = op < 3 ? 32 : 48;
+  const size_t esz = (op < 3 || op == 6) ? 32 : 48;
   void *da = nullptr, *db = nullptr, *dc = nullptr;
   struct Free3 {   // the temporaries go away on every path, error returns included
     void **a, **b, **c;
@@ -298,6 +301,8 @@ extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const ui
     case 3: hipLaunchKernelGGL((field_op_kernel<FpP, 0>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
     case 4: hipLaunchKernelGGL((field_op_kernel<FpP, 1>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
     case 5: hipLaunchKernelGGL((field_op_kernel<FpP, 2>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 6: hipLaunchKernelGGL((field_op_kernel<FrP, 3>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
+    case 7: hipLaunchKernelGGL((field_op_kernel<FpP, 3>), g, blk, 0, ctx->stream, pa, pb, pc, n); break;
   }
   PM_HIP(ctx, hipGetLastError());
   PM_HIP(ctx, hipMemcpyAsync(out, dc, n * esz, hipMemcpyDeviceToHost, ctx->stream));

@@ -36,6 +36,7 @@
 
 #include "context.h"
 #include "ec.cuh"
+#include "field_inv.cuh"
 #include "host_field.h"
 #include "msm_sort.cuh"
 
@@ -84,18 +85,8 @@ __global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scr
     for (int k = 0; k < 14; ++k) nz |= ld_fp_limbs(scratch + 16 * i + 8).l[k];
     if (nz) acc = fe_mul<FpP>(acc, zzz);
   }
-  // acc^(p-2)
-  Fp inv = one, base = acc;
-  {
-    constexpr u32 E[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
-                           0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
-    for (int w = 0; w < 12; ++w) {
-      for (int bit = 0; bit < 32; ++bit) {
-        if ((E[w] >> bit) & 1) inv = fe_mul<FpP>(inv, base);
-        base = fe_sqr<FpP>(base);
-      }
-    }
-  }
+  // 1 / acc (binary GCD, field_inv.cuh; r01 / r02: acc^(p-2), 381 dependent squarings per thread)
+  Fp inv = fe_inv_dev<FpP>(acc);
   for (u32 j = per; j-- > 0;) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) continue;

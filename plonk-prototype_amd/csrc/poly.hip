@@ -9,10 +9,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "context.h"
+#include "field_inv.cuh"
 #include "host_field.h"
 #include "ntt_kernels.cuh"
 #include "poly_common.cuh"
@@ -426,13 +428,11 @@ __global__ void ruffini_shift_kernel(const u32x4* coeffs, u32x4* out, size_t m) 
 }
 
 // ------------------------------------------------------------------ batch inversion
-// Montgomery's trick per thread over `L` elements taken with stride T (coalesced), one Fermat
-// inversion per thread.  Forms: u = a * 2^5 (ABI -> device form, a shift and a weak reduction, no
+// Montgomery's trick per thread over `L` elements taken with stride T (coalesced), one inversion per thread.  Forms: u = a * 2^5 (ABI -> device form, a shift and a weak reduction, no
 // product); prefix products in device form; the inverse of the thread's product is moved to ABI form
 // once, after which inverse(ABI) x prefix(device) and inverse(ABI) x u(device) both stay in ABI form:
-// 3 products per element (r01: 6) + ~325 per thread for x^(r-2) with 4-bit windows and dedicated
-// squarings (r01: 380 general products).  The floor is the serial exponentiation: one thread's ~325
-// dependent products are ~0.15 ms however the elements are distributed.
+// 3 products per element (r01: 6) + one binary-GCD inversion per thread (r03; r02: x^(r-2), ~325 dependent products,
+// a 0.15 ms latency floor however the elements were distributed).
 __global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, size_t n, u32 L, u32x4* scratch) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,35 +448,10 @@ __global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, size_t n, 
     st_tw(scratch, i, acc);                    // product of the earlier non-zero elements
     if (nz) acc = fe_mul<FrP>(acc, abi_to_dev(raw));
   }
-  // acc^(r-2), 4-bit fixed windows from the top: 252 squarings + 63 table products + 14 to build the table
-  Fr inv;
-  {
-    Fr tab[16];
-    tab[0] = one;
-    tab[1] = acc;
-#pragma unroll
-    for (int i = 2; i < 16; ++i) tab[i] = fe_mul<FrP>(tab[i - 1], acc);
-    constexpr u32 E[8] = {0xffffffffu, 0xfffffffeu, 0xfffe5bfeu, 0x53bda402u,
-                          0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};  // r - 2
-    inv = one;
-    for (int w = 7; w >= 0; --w) {
-      for (int nib = 7; nib >= 0; --nib) {
-        if (!(w == 7 && nib == 7)) {
-          inv = fe_sqr<FrP>(inv); inv = fe_sqr<FrP>(inv); inv = fe_sqr<FrP>(inv); inv = fe_sqr<FrP>(inv);
-        }
-        const u32 d = (E[w] >> (4 * nib)) & 15u;
-        // a table in registers indexed by a runtime value would spill: select with a compare chain
-        Fr m = tab[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) m.l[q] = d == (u32)i ? tab[i].l[q] : m.l[q];
-        }
-        if (d) inv = fe_mul<FrP>(inv, m);
-      }
-    }
-  }
-  inv = fe_mul<FrP>(inv, fe_pow2<FrP, 256>());   // device form -> ABI form
+  // 1 / acc by the binary GCD of field_inv.cuh (~16 k instructions; r01 / r02: acc^(r-2), ~76 k and 57 % of a thread's
+  // work).  acc = x R' (device form): the integer inverse is x^-1 / R'; times R R'^2 (and the product's 1 / R') gives
+  // x^-1 R, the ABI form the back-substitution wants
+  Fr inv = fe_mul<FrP>(fe_inv_int<FrP>(fe_canon_limbs<FrP>(acc)), fe_pow2<FrP, 256 + 2 * 261>());
   for (u32 j = L; j-- > 0;) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) continue;
@@ -769,7 +744,8 @@ extern "C" int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, voi
   // enough threads to fill the chip, at most 64 elements per thread
   // one Fermat inversion (~380 products) per thread: 64 elements per thread amortise it to ~6
   // products per element; below 2^22 elements keep at least one wave per SIMD instead
-  const size_t want_threads = std::max<size_t>((n + 63) / 64, std::min<size_t>(n, (size_t)ctx->num_cus * 256));
+  const size_t per = 32;   // elements per thread and inversion (2^22: 271 us with 32, 287 with 64, 318 with 16)
+  const size_t want_threads = std::max<size_t>((n + per - 1) / per, std::min<size_t>(n, (size_t)ctx->num_cus * 256));
   const unsigned blocks = (unsigned)((want_threads + 255) / 256);
   const size_t T = (size_t)blocks * 256;
   const u32 L = (u32)((n + T - 1) / T);

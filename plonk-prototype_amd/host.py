@@ -214,7 +214,7 @@ class Context:
         a = np.ascontiguousarray(a, dtype=np.uint64)
         b = np.ascontiguousarray(b, dtype=np.uint64)
         out = np.empty_like(a)
-        limbs = 4 if op < 3 else 6
+        limbs = 4 if (op < 3 or op == 6) else 6
         self._check(self._lib.pm_test_field_op(self._h, op, _p(a), _p(b), _p(out), a.size // limbs))
         return out
 

@@ -26,3 +26,18 @@ def test_mul_add_sub(ctx, oracle, field):
     for op, fn in [(0, lambda x, y: x * y % mod), (1, lambda x, y: (x + y) % mod), (2, lambda x, y: (x - y) % mod)]:
         got = limbs_to_ints(from_mont(ctx.field_op(base + op, am, bm)))
         assert got == [fn(x, y) for x, y in zip(a, b)], (field, op)
+
+
+@pytest.mark.parametrize("field", ["fr", "fp"])
+def test_inverse(ctx, oracle, field):
+    """The binary-GCD inversion of csrc/field_inv.cuh against pow(x, -1, m): edge values (0 stays 0, 1, m - 1, powers of
+    two, small numbers whose approximations are exact from the first round on) and random ones."""
+    mod, nl, op = (B.R_MOD, 4, 6) if field == "fr" else (B.P_MOD, 6, 7)
+    rng = B.sample_fr(5 if field == "fr" else 6, 3000)
+    vals = [v * 0x9E3779B97F4A7C15 % mod for v in rng] if field == "fp" else rng
+    a = _edge_values(mod) + list(range(2, 40)) + [mod - k for k in range(3, 20)] + [(1 << k) % mod for k in range(1, 384, 7)] + vals
+    to_mont = oracle.fr_to_mont if field == "fr" else oracle.fp_to_mont
+    from_mont = oracle.fr_from_mont if field == "fr" else oracle.fp_from_mont
+    am = to_mont(ints_to_limbs(a, nl))
+    got = limbs_to_ints(from_mont(ctx.field_op(op, am, am)))
+    assert got == [pow(x, -1, mod) if x else 0 for x in a], field
