@@ -276,9 +276,16 @@ def main():
             for _ in range(5):
                 ctx.fr_ntt_fourstep_dev(zb.data_ptr(), stage.data_ptr(), kb, 1, 0, 0)
             ctx.sync()
-            big["fourstep_world1"] = {"ms_per_transform": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+            four_ms = (time.perf_counter() - t0) / 5 * 1e3
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.fr_ntt_fourstep_dev(zb.data_ptr(), stage.data_ptr(), kb, 1, 0, pa.NTT_TRANSPOSED)
+            ctx.sync()
+            four_t_ms = (time.perf_counter() - t0) / 5 * 1e3
+            big["fourstep_world1"] = {"ms_per_transform": round(four_ms, 3),
+                                      "ms_per_transform_transposed_order": round(four_t_ms, 3),
                                       "equals_single_gpu_plan": four_ok,
-                                      "note": "pm_fr_ntt_fourstep_dev with world = 1: three pack + unpack transposes and four sub-transform passes; over several GPUs each transpose adds one all-to-all (not measurable on one GPU)"}
+                                      "note": "pm_fr_ntt_fourstep_dev with world = 1: three transposes (two with PM_NTT_TRANSPOSED: the result stays in the block-transposed order a pointwise consumer accepts) and four sub-transform passes; over several GPUs each transpose adds one all-to-all (not measurable on one GPU)"}
             del xb, yb, zb, stage
         ntt_extra = {"fwd_inv_2^24": big, "pcie_inclusive": {"ms_per_transform": round(e2e * 1e3, 3), "butterflies_per_s": (n // 2) * k / e2e,
                                         "note": "pm_fr_ntt with pageable host buffers: H2D + transform + D2H; never `value`",

@@ -73,6 +73,7 @@ typedef enum {
 #define PM_NTT_FORWARD 0u
 #define PM_NTT_INVERSE 1u /* use group_gen_inv and scale by size_inv (ifft) */
 #define PM_NTT_COSET 2u   /* fft: pre-scale a[i] *= 7^i ; with INVERSE: post-scale a[i] *= 7^-i */
+#define PM_NTT_TRANSPOSED 4u /* pm_fr_ntt_fourstep_dev only: block-transposed order between a forward and an inverse transform */
 
 /* pm_g1_msm scalar_form */
 #define PM_SCALAR_MONTGOMERY 0u /* dusk `&[BlsScalar]` memory */
@@ -125,7 +126,11 @@ int pm_fr_ntt_dev(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride
  * d_recv comes from rank p; it is called with the library's stream idle and must return with the data in place;
  * non-zero = failure); NULL uses the context's RCCL communicator (pm_comm_init) on the context's stream.
  * world must be a power of two dividing both 2^(log_n / 2) and 2^(log_n - log_n / 2); 2 <= log_n <= 26.
- * Runs on the context's own stream.  Mirrors nothing upstream: dusk-plonk is single-device. */
+ * Runs on the context's own stream.  Mirrors nothing upstream: dusk-plonk is single-device.
+ * PM_NTT_TRANSPOSED saves the third all-to-all where the natural order is not needed (evaluations that are only
+ * consumed pointwise, e.g. the quotient): a FORWARD transform then leaves X[k2 N1 + k1] at position k1 N2 + k2 of the
+ * N1 x N2 row-major matrix (N1 = 2^(log_n / 2), rows block-distributed: rank r holds k1 in [r N1 / W, (r + 1) N1 / W)),
+ * and an INVERSE transform takes exactly that layout and returns natural order. */
 typedef int (*pm_alltoall_fn)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
 int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t log_n, uint32_t world,
                            uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user);

@@ -6,7 +6,7 @@ Host-side mirror of the dusk-plonk / dusk-bls12_381 interfaces the reference dep
 runs in hand-written HIP kernels; importing works without a GPU, but creating a
 :class:`Context` raises unless a gfx950 device and the built library are present.
 """
-from ._lib import (BackendMissing, NTT_COSET, NTT_INVERSE, SCALAR_CANONICAL,  # noqa: F401
+from ._lib import (BackendMissing, NTT_COSET, NTT_INVERSE, NTT_TRANSPOSED, SCALAR_CANONICAL,  # noqa: F401
                    SCALAR_MONTGOMERY, load, LIB_PATH)
 from .host import (CommitKey, Context, DeviceVector, Error, EvaluationDomain, Polynomial,  # noqa: F401
                    msm_variable_base,

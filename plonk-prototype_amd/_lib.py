@@ -133,6 +133,7 @@ PM_ERR_BUSY = -8
 
 NTT_INVERSE = 1
 NTT_COSET = 2
+NTT_TRANSPOSED = 4   # pm_fr_ntt_fourstep_dev: block-transposed order between a forward and an inverse transform
 SCALAR_MONTGOMERY = 0
 SCALAR_CANONICAL = 1
 

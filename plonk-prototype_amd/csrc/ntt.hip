@@ -647,7 +647,7 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
                                       uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user) {
   if (!ctx || !d_inout || !d_stage) return PM_ERR_BAD_ARG;
   if (world == 0 || (world & (world - 1)) || rank >= world) return PM_ERR_BAD_ARG;
-  if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET)) return PM_ERR_BAD_ARG;
+  if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET | PM_NTT_TRANSPOSED)) return PM_ERR_BAD_ARG;
   if (log_n < 2 || log_n > 26) return PM_ERR_DOMAIN_TOO_LARGE;   // 32-bit exponents of the two-level tables
   const uint32_t l1 = log_n / 2, l2 = log_n - l1;
   const uint32_t n1 = 1u << l1, n2 = 1u << l2;
@@ -682,19 +682,26 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
     if (rc) return rc;
   }
   const FsMul none{0, nullptr, nullptr, 0, 0};
-  // one transpose: slice [R_loc][C] of a row-distributed [R][C] matrix -> slice [C / W][R] of its transpose
-  auto transpose = [&](u32 R_loc, u32 C, const FsMul& on_pack, const FsMul& on_unpack) -> int {
+  // one transpose: slice [R_loc][C] of a row-distributed [R][C] matrix -> slice [C / W][R] of its transpose.  The
+  // result is in *where: x -- or, with one rank and no factor on the way in, the stage buffer itself (the unpack
+  // would be a plain copy: the next sub-transform reads it from there; `keep_in_x` forces the copy)
+  auto transpose = [&](const u32x4* from, u32 R_loc, u32 C, const FsMul& on_pack, const FsMul& on_unpack, bool keep_in_x,
+                       const u32x4** where) -> int {
     const u32 Cw = C / world;
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
       ProfScope prof(ctx, st, "ntt_fourstep_transpose");
-      hipLaunchKernelGGL(fs_pack_kernel, dim3((C + 31) / 32, (R_loc + 31) / 32), dim3(256), 0, st, (const u32x4*)x, R_loc, C, Cw,
+      hipLaunchKernelGGL(fs_pack_kernel, dim3((C + 31) / 32, (R_loc + 31) / 32), dim3(256), 0, st, from, R_loc, C, Cw,
                          send, on_pack);
       PM_HIP(ctx, hipGetLastError());
       if (world > 1 && !exchange) {
         int rc = comm_alltoall(ctx, send, recv, (size_t)Cw * R_loc * 32, st);
         if (rc) return rc;
       }
+    }
+    if (world == 1 && on_unpack.mode == 0 && !keep_in_x) {
+      *where = send;
+      return PM_OK;
     }
     if (world > 1 && exchange) {   // the callback sees finished data and returns when the peers' blocks are in place
       {
@@ -709,26 +716,39 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
     hipLaunchKernelGGL(fs_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u32x4*)recv, R_loc, world,
                        Cw, x, on_unpack);
     PM_HIP(ctx, hipGetLastError());
+    *where = x;
     return PM_OK;
   };
   const uint32_t sub = inverse ? PM_NTT_INVERSE : 0;
-  // 1: [N1/W][N2] -> [N2/W][N1]  (coset_fft: x[n] *= g^n on the way out)
-  FsMul pre = none;
-  if (coset && !inverse) pre = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (n1 / world)};
-  int rc = transpose(n1 / world, n2, pre, none);
+  // PM_NTT_TRANSPOSED: a forward transform leaves its result as the [N1 / W][N2] matrix of step 4 -- X[k2 N1 + k1] at
+  // position k1 N2 + k2, rank r holding rows k1 in [r N1 / W, (r + 1) N1 / W) -- and skips the third all-to-all; an
+  // inverse transform TAKES that layout: with the two factors swapped it is exactly the state after step 1.  What sits
+  // between the two in a prover (the pointwise quotient) does not care about the order.
+  const bool transposed = flags & PM_NTT_TRANSPOSED;
+  const uint32_t la = transposed && inverse ? l2 : l1, lb = log_n - la;   // rows x columns of the input matrix
+  const uint32_t na = 1u << la, nb = 1u << lb;
+  const u32x4* cur = x;
+  int rc = PM_OK;
+  if (!(transposed && inverse)) {
+    // 1: [A/W][B] -> [B/W][A]  (coset_fft: x[n] *= g^n on the way out)
+    FsMul pre = none;
+    if (coset && !inverse) pre = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (na / world)};
+    rc = transpose(x, na / world, nb, pre, none, false, &cur);
+    if (rc) return rc;
+  }
+  // 2: B/W transforms of size A over the columns
+  rc = pm_fr_ntt_dev(ctx, cur, na, na, x, na, la, nb / world, sub, nullptr);
   if (rc) return rc;
-  // 2: N2/W transforms of size N1 over the columns
-  rc = pm_fr_ntt_dev(ctx, x, n1, n1, x, n1, l1, n2 / world, sub, nullptr);
+  // 3: [B/W][A] -> [A/W][B], element (j, k1) times w^(j k1) on the way out
+  const FsMul tw{1, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, rank * (nb / world)};
+  rc = transpose(x, nb / world, na, tw, none, false, &cur);
   if (rc) return rc;
-  // 3: [N2/W][N1] -> [N1/W][N2], element (j, k1) times w^(j k1) on the way out
-  const FsMul tw{1, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, rank * (n2 / world)};
-  rc = transpose(n2 / world, n1, tw, none);
+  // 4: A/W transforms of size B over the rows
+  rc = pm_fr_ntt_dev(ctx, cur, nb, nb, x, nb, lb, na / world, sub, nullptr);
   if (rc) return rc;
-  // 4: N1/W transforms of size N2 over the rows
-  rc = pm_fr_ntt_dev(ctx, x, n2, n2, x, n2, l2, n1 / world, sub, nullptr);
-  if (rc) return rc;
-  // 5: [N1/W][N2] (k1, k2) -> [N2/W][N1] (k2, k1) = natural order  (coset_ifft: X[k] *= g^-k on the way in)
+  if (transposed && !inverse) return PM_OK;
+  // 5: [A/W][B] (k1, k2) -> [B/W][A] (k2, k1) = natural order  (coset_ifft: X[k] *= g^-k on the way in)
   FsMul post = none;
-  if (coset && inverse) post = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (n2 / world)};
-  return transpose(n1 / world, n2, none, post);
+  if (coset && inverse) post = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (nb / world)};
+  return transpose(x, na / world, nb, none, post, true, &cur);
 }

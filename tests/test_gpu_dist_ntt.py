@@ -46,6 +46,17 @@ def _worker(rank, world, port, log_ns, q):
                 got = plan(mine, flags).cpu().numpy().view(np.uint64)
                 exp = ctx.fr_ntt(full, log_n, flags)[rank * blk:(rank + 1) * blk]
                 ok = ok and bool(np.array_equal(got, exp))
+            # PM_NTT_TRANSPOSED: the forward result stays in the [N1 / W][N2] matrix order of the last sub-transform
+            # (one all-to-all less): X[k2 N1 + k1] at k1 N2 + k2; the inverse takes that order and returns natural order
+            l1 = log_n // 2
+            n1, n2 = 1 << l1, 1 << (log_n - l1)
+            for cos in (0, 2):
+                tr = plan(mine, cos | 4)
+                nat = ctx.fr_ntt(full, log_n, cos).reshape(n2, n1, 4)            # [k2][k1]
+                exp_t = np.ascontiguousarray(nat.transpose(1, 0, 2)).reshape(n, 4)[rank * blk:(rank + 1) * blk]
+                ok = ok and bool(np.array_equal(tr.cpu().numpy().view(np.uint64), exp_t))
+                back = plan(tr, cos | 1 | 4)
+                ok = ok and bool(torch.equal(back, mine))
             assert torch.equal(mine.cpu(), torch.from_numpy(full[rank * blk:(rank + 1) * blk].view(np.int64)))   # input untouched
         q.put((rank, ok))
         ctx.close()
@@ -85,6 +96,14 @@ def test_four_step_ntt_single_rank(ctx, oracle, log_n):
     # forward then inverse is the identity
     back = plan(plan(x, 2), 3)
     assert torch.equal(back, x)
+    # ... also through the block-transposed order (two transposes per transform instead of three)
+    l1 = log_n // 2
+    n1, n2 = 1 << l1, 1 << (log_n - l1)
+    for cos in (0, 2):
+        tr = plan(x, cos | 4)
+        nat = oracle.fr_ntt(a, log_n, cos, 4).reshape(n2, n1, 4)
+        assert np.array_equal(tr.cpu().numpy().view(np.uint64), np.ascontiguousarray(nat.transpose(1, 0, 2)).reshape(n, 4)), cos
+        assert torch.equal(plan(tr, cos | 1 | 4), x), cos
 
 
 def test_four_step_ntt_2_20_equals_the_library_plan(ctx, oracle):
@@ -107,7 +126,7 @@ def test_four_step_native_entry_point_checks_its_arguments(ctx):
     import plonk_prototype_amd as pa
     x = torch.zeros((256, 4), dtype=torch.int64, device="cuda")
     st = torch.zeros((512, 4), dtype=torch.int64, device="cuda")
-    for world, rank, log_n, flags in ((3, 0, 8, 0), (2, 2, 8, 0), (32, 0, 8, 0), (1, 0, 1, 0), (1, 0, 27, 0), (1, 0, 8, 4)):
+    for world, rank, log_n, flags in ((3, 0, 8, 0), (2, 2, 8, 0), (32, 0, 8, 0), (1, 0, 1, 0), (1, 0, 27, 0), (1, 0, 8, 8)):
         with pytest.raises(pa.Error):
             ctx.fr_ntt_fourstep_dev(x.data_ptr(), st.data_ptr(), log_n, world, rank, flags)
     with pytest.raises(pa.Error) as e:                      # two ranks, no callback, no communicator
