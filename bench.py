@@ -32,6 +32,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; this script's stdout carries exactly
+    one JSON line, so file descriptor 1 points at stderr while a communicator is being made."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +126,8 @@ def main():
     native_comm = False
     if world > 1 and backend == "nccl":
         try:
-            ctx.comm_init(rank, world, coll_dev)
+            with stdout_to_stderr():
+                ctx.comm_init(rank, world, coll_dev)
             ok_local = 1
         except Exception as e:                                   # noqa: BLE001
             print(f"[bench] rank {rank}: pm_comm_init failed ({e}); using torch.distributed", file=sys.stderr)
@@ -387,8 +404,9 @@ def main():
             # time of the library's exchange on a ONE-rank communicator: staging copies + ncclAllGather + fold)
             exch = None
             try:
-                ctx.comm_init(0, 1)
-                ctx.g1_allgather_fold(res.reshape(1, 18))
+                with stdout_to_stderr():
+                    ctx.comm_init(0, 1)
+                    ctx.g1_allgather_fold(res.reshape(1, 18))
                 t0 = time.perf_counter()
                 for _ in range(20):
                     ctx.g1_allgather_fold(res.reshape(1, 18))

@@ -3,7 +3,7 @@
 # Counters go in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), and never
 # together with sys/hip/hsa tracing.  Output: gpurun_out/$1/pmc_*/ (csv).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

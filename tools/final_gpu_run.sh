@@ -2,7 +2,7 @@
 # One consolidated GPU validation (run through gpurun): tests, bench, smoke, rocprof stats, PMC.
 # Everything is written under gpurun_out/$1/; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r02z}
+TAG=${1:-r03z}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
