@@ -154,6 +154,8 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
                           &ctx->msm_scalars, &ctx->poly_ws, &ctx->poly_tab})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
+  if (ctx->msm_side) (void)hipStreamDestroy(ctx->msm_side);
+  for (hipEvent_t e : ctx->msm_events) (void)hipEventDestroy(e);
   for (StreamOrder* o : {&ctx->ord_ntt, &ctx->ord_msm, &ctx->ord_poly})
     if (o->ev) (void)hipEventDestroy(o->ev);
   prof_collect(ctx);
@@ -237,6 +239,10 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
   if (!strcmp(key, "msm_lb")) {
     if (value < 0 || value > 1024 || (value & (value - 1))) return set_err(ctx, PM_ERR_BAD_ARG, "msm_lb must be a power of two");
     ctx->opt_msm_lb = value;
+    return PM_OK;
+  }
+  if (!strcmp(key, "msm_pipeline")) {
+    ctx->opt_msm_pipeline = value != 0;
     return PM_OK;
   }
   if (!strcmp(key, "ntt_xcd")) {

@@ -65,6 +65,8 @@ struct pm_ctx {
   pm::DeviceBuffer msm_ws;
   pm::DeviceBuffer msm_ctl;                             // control block of the bucket fill (msm_sort.cuh): zero when idle
   unsigned msm_ctl_cap = 0;                             // partitions it is laid out for
+  hipStream_t msm_side = nullptr;                       // second stream of the piece pipeline of a batched MSM (msm.hip)
+  std::vector<hipEvent_t> msm_events;                   // "piece i has left the accumulate"
   pm::DeviceBuffer msm_scalars;
   pm::DeviceBuffer poly_ws;                             // scratch of the polynomial helpers
   pm::DeviceBuffer poly_tab;                            // power tables of pm_fr_poly_ruffini_dev
@@ -99,6 +101,7 @@ struct pm_ctx {
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_max_pairs = 0;    // 0 = 2^31 - 1; a batched MSM with more (digit, point) pairs runs in halves
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
+  long opt_msm_pipeline = 0;     // 1: a batched MSM runs as up to four pieces on two streams (measured: loses, see msm.hip)
   int num_cus = 256;
 };
 

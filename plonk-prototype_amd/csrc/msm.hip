@@ -579,33 +579,23 @@ static bool msm_debug() {
     }                                                                           \
   } while (0)
 
-int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars, size_t sc_stride,
-            u32 batch, u32 scalar_form, uint64_t* out_xyz /* batch x 18 */, hipStream_t st) {
-  if (batch == 0) return PM_OK;
-  if (n == 0) {
-    for (u32 j = 0; j < batch; ++j) write_projective(out_xyz + 18 * j, host::xyzz_identity());
-    return PM_OK;
-  }
-  if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
-  if (bases->table_c && (size_t)bases->n * ((256 + bases->table_c - 1) / bases->table_c) > 0x7fffffffu)
-    return set_err(ctx, PM_ERR_BAD_ARG, "window table too large for 31-bit point indices");
-  OrderScope order_scope(ctx, ctx->ord_msm, st);   // msm_ws and the pinned result buffer are shared by all streams
-  if (order_scope.rc) return order_scope.rc;
+// What the host needs to finish one piece of an MSM call (a sub-batch that went through the kernels on its own).
+struct MsmPiece {
+  u32 batch, nsets, c, n_levels, log_lb, nsets_all;
+  const u32* hw;        // pinned host memory: (n_levels + 1) x nsets_all XYZZ records
+};
+// One piece: every kernel of the pipeline plus the copy of its (n_levels + 1) x nsets_all result points, enqueued on
+// `st` -- no host synchronisation.  ws == nullptr: nothing is launched, only *need_ws / *need_pinned are set (bytes of
+// device workspace and of pinned host memory a piece of this shape takes).  front_done (optional) is recorded after the
+// last accumulate level: from there on the piece only reads its own buckets (not the control block of the bucket fill).
+static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars, size_t sc_stride,
+                     u32 batch, u32 scalar_form, hipStream_t st, hipEvent_t front_done, char* ws, size_t* need_ws,
+                     void* pinned, size_t* need_pinned, MsmPiece* piece) {
   MsmGeom g = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, batch);
   if (g.bins > SORT_MAX_BINS || g.rbits > SORT_MAX_RBITS || g.ts == 0)
     return set_err(ctx, PM_ERR_BAD_ARG, "window width outside what the bucket fill is laid out for");
   const size_t m = n * batch * g.nwin;  // (key, value) pairs at most: one per non-zero digit
   const u32 nsets_all = g.nsets * batch;
-  if (m > (ctx->opt_msm_max_pairs ? (size_t)ctx->opt_msm_max_pairs : (size_t)0x7fffffffu)) {
-    // pair indices are 31-bit: a batch too large for one pass (15 key polynomials of 2^24 coefficients) goes
-    // through in halves
-    if (batch == 1) return set_err(ctx, PM_ERR_LENGTH, "n * windows exceeds 2^31 pairs");
-    const u32 half = batch / 2;
-    int rc = msm_run(ctx, bases, offset, n, d_scalars, sc_stride, half, scalar_form, out_xyz, st);
-    if (rc) return rc;
-    return msm_run(ctx, bases, offset, n, (const char*)d_scalars + (size_t)half * sc_stride * 32, sc_stride, batch - half,
-                   scalar_form, out_xyz + 18 * half, st);
-  }
   // Entries per thread in the big kernel (measured, profiles/r01_msm_sweep.txt, r02_msm_sweep.txt): about
   // four times the mean run length m / #buckets when the grid allows it (then a run is split over at
   // most two neighbouring lanes and the in-wave join costs one addition), at least 128, and never so
@@ -683,28 +673,16 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
   std::vector<size_t> o_lvl(n_levels);
   for (u32 k = 0; k < n_levels; ++k) o_lvl[k] = take((size_t)(k + 3) * nsets_all * lvl_groups[k] * 256);
   const size_t o_win = take((size_t)(n_levels + 1) * nsets_all * 256);
-  int rc = ensure_buffer(ctx, ctx->msm_ws, off);
-  if (rc) return rc;
-  char* ws = (char*)ctx->msm_ws.ptr;
-  u32 *keys1 = (u32*)(ws + o_keys1), *vals1 = (u32*)(ws + o_vals1);
-  // control block of the bucket fill: zero when idle (the histogram kernel restores that), zeroed when (re)allocated
-  if (ctx->msm_ctl_cap < g.np) {
-    const u32 cap = std::max<u32>(g.np, 1u << 16);
-    rc = ensure_buffer(ctx, ctx->msm_ctl, sort_ctl_words(cap) * 4);
-    if (rc) return rc;
-    PM_HIP(ctx, hipMemsetAsync(ctx->msm_ctl.ptr, 0, ctx->msm_ctl.bytes, st));
-    ctx->msm_ctl_cap = cap;
+  const size_t pinned_bytes = (size_t)(n_levels + 1) * nsets_all * 256;
+  if (!ws) {
+    *need_ws = off;
+    *need_pinned = pinned_bytes;
+    return PM_OK;
   }
+  u32 *keys1 = (u32*)(ws + o_keys1), *vals1 = (u32*)(ws + o_vals1);
   g.ctl_cap = ctx->msm_ctl_cap;   // the block's layout is fixed per allocation, whatever this MSM's partition count
   u32* ctl = (u32*)ctx->msm_ctl.ptr;
   u32x4* buckets = (u32x4*)(ws + o_buckets);
-
-  if (ctx->msm_host_pinned_bytes < (size_t)(n_levels + 1) * nsets_all * 256) {
-    if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
-    ctx->msm_host_pinned = nullptr;
-    ctx->msm_host_pinned_bytes = std::max<size_t>(64, (size_t)(n_levels + 1) * nsets_all) * 256;
-    PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, ctx->msm_host_pinned_bytes, hipHostMallocDefault));
-  }
 
   // 1 + 2 bucket fill (msm_sort.cuh)
   {
@@ -785,6 +763,7 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
     PM_HIP(ctx, hipGetLastError());
   }
+  if (front_done) PM_HIP(ctx, hipEventRecord(front_done, st));
   // 4 bucket reduce: level 1 over the buckets, then the small levels (see msm_bucket_wave_kernel)
   u32x4* win = (u32x4*)(ws + o_win);
   const size_t slot = (size_t)nsets_all * 16;   // u32x4 per slot of o_win
@@ -826,30 +805,131 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
     }
   }
   PM_HIP(ctx, hipGetLastError());
-  // 5 host fold: per set F_0 + 32 LB (F_1 + 32 (F_2 + 32 F_3)), then the windows
-  PM_HIP(ctx, hipMemcpyAsync(ctx->msm_host_pinned, ws + o_win, (size_t)(n_levels + 1) * nsets_all * 256,
-                             hipMemcpyDeviceToHost, st));
-  PM_HIP(ctx, hipStreamSynchronize(st));
-  const u32* hw = (const u32*)ctx->msm_host_pinned;
+  PM_HIP(ctx, hipMemcpyAsync(pinned, ws + o_win, pinned_bytes, hipMemcpyDeviceToHost, st));
+  piece->batch = batch;
+  piece->nsets = g.nsets;
+  piece->c = g.c;
+  piece->n_levels = n_levels;
+  piece->log_lb = log_lb;
+  piece->nsets_all = nsets_all;
+  piece->hw = (const u32*)pinned;
+  return PM_OK;
+}
+// 5 host fold of a piece whose copy has arrived: per set F_0 + 32 LB (F_1 + 32 (F_2 + 32 F_3)), then the windows
+static void msm_fold(const MsmPiece& pc, XYZZ* totals) {
+  const u32* hw = pc.hw;
   auto set_total = [&](size_t set) {
-    XYZZ acc = xyzz_to_host(hw + 64 * ((size_t)n_levels * nsets_all + set));
-    for (u32 k = n_levels; k-- > 0;) {
-      const u32 dbl = k == 0 ? 5 + log_lb : 5;   // log2(GROUP) per level
+    XYZZ acc = xyzz_to_host(hw + 64 * ((size_t)pc.n_levels * pc.nsets_all + set));
+    for (u32 k = pc.n_levels; k-- > 0;) {
+      const u32 dbl = k == 0 ? 5 + pc.log_lb : 5;   // log2(GROUP) per level
       for (u32 d = 0; d < dbl; ++d) acc = host::xyzz_double(acc);
-      acc = host::xyzz_add(acc, xyzz_to_host(hw + 64 * ((size_t)k * nsets_all + set)));
+      acc = host::xyzz_add(acc, xyzz_to_host(hw + 64 * ((size_t)k * pc.nsets_all + set)));
     }
     return acc;
   };
-  std::vector<XYZZ> totals(batch);
-  for (u32 j = 0; j < batch; ++j) {
+  for (u32 j = 0; j < pc.batch; ++j) {
     XYZZ total = host::xyzz_identity();
-    for (u32 w = g.nsets; w-- > 0;) {  // one set (table mode): no window doublings at all
-      if (w + 1 < g.nsets)
-        for (u32 k = 0; k < g.c; ++k) total = host::xyzz_double(total);
-      total = host::xyzz_add(total, set_total((size_t)j * g.nsets + w));
+    for (u32 w = pc.nsets; w-- > 0;) {  // one set (table mode): no window doublings at all
+      if (w + 1 < pc.nsets)
+        for (u32 k = 0; k < pc.c; ++k) total = host::xyzz_double(total);
+      total = host::xyzz_add(total, set_total((size_t)j * pc.nsets + w));
     }
     totals[j] = total;
   }
+}
+
+// A call with `batch` scalar vectors normally runs as ONE piece (more only when the 31-bit pair indices force it).
+// Option "msm_pipeline" = 1 runs it as up to four pieces in a two-stream software pipeline instead -- piece i + 1's
+// bucket fill and accumulate start when piece i's accumulate is done, so that piece i's tail (bucket reduction, window
+// sums, result copy: ~0.8 ms of kernels that are latency-bound at one or two waves per SIMD) would run under the next
+// piece's accumulate.  Built, tested (tests/test_gpu_msm.py runs both settings) and MEASURED TO
+// LOSE: 2^20-gate proof 36.5 ms as one piece, 44.1 ms as pieces (profiles/r03_msm_pipeline_ab.txt).  The accumulate
+// grid is sized to fill the chip exactly once (two waves per SIMD at 236 VGPRs); a tail kernel that holds even a few
+// of those slots when the next accumulate is dispatched pushes that many of its workgroups into a second round, which
+// costs a whole chunk time (~2 ms) however few they are.  Inside one proof nothing else can fill the tails either:
+// round k + 1's scalars depend on round k's commitments through the transcript.  Two PROOFS in flight do recover the
+// idle slots (bench.py, two_contexts_ms_per_proof), because there whole accumulates alternate.
+int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const void* d_scalars, size_t sc_stride,
+            u32 batch, u32 scalar_form, uint64_t* out_xyz /* batch x 18 */, hipStream_t st) {
+  if (batch == 0) return PM_OK;
+  if (n == 0) {
+    for (u32 j = 0; j < batch; ++j) write_projective(out_xyz + 18 * j, host::xyzz_identity());
+    return PM_OK;
+  }
+  if (n > 0x7fffffffu) return set_err(ctx, PM_ERR_BAD_ARG, "n >= 2^31");
+  if (bases->table_c && (size_t)bases->n * ((256 + bases->table_c - 1) / bases->table_c) > 0x7fffffffu)
+    return set_err(ctx, PM_ERR_BAD_ARG, "window table too large for 31-bit point indices");
+  OrderScope order_scope(ctx, ctx->ord_msm, st);   // msm_ws and the pinned result buffer are shared by all streams
+  if (order_scope.rc) return order_scope.rc;
+  // pieces: pair indices are 31-bit, so a piece holds at most 2^31 - 1 (digit, point) pairs (the 15 key polynomials of
+  // a 2^24-gate circuit do not fit one)
+  const size_t pairs_per_msm = n * make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, 1).nwin;
+  const size_t max_pairs = ctx->opt_msm_max_pairs ? (size_t)ctx->opt_msm_max_pairs : (size_t)0x7fffffffu;
+  if (pairs_per_msm > max_pairs) return set_err(ctx, PM_ERR_LENGTH, "n * windows exceeds 2^31 pairs");
+  u32 npieces = ctx->opt_msm_pipeline ? std::min<u32>(batch, 4u) : 1u;
+  while ((size_t)((batch + npieces - 1) / npieces) * pairs_per_msm > max_pairs) ++npieces;
+  const u32 per_piece = (batch + npieces - 1) / npieces;
+  npieces = (batch + per_piece - 1) / per_piece;
+  // sizes: all pieces but the last have per_piece vectors
+  size_t region = 0, pin_each = 0;
+  int rc = msm_piece(ctx, bases, offset, n, d_scalars, sc_stride, per_piece, scalar_form, st, nullptr, nullptr, &region, nullptr,
+                     &pin_each, nullptr);
+  if (rc) return rc;
+  region = align_up(region, 4096);
+  rc = ensure_buffer(ctx, ctx->msm_ws, npieces > 1 ? 2 * region : region);
+  if (rc) return rc;
+  if (ctx->msm_host_pinned_bytes < pin_each * npieces) {
+    if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
+    ctx->msm_host_pinned = nullptr;
+    ctx->msm_host_pinned_bytes = std::max<size_t>(64 * 256, pin_each * npieces);
+    PM_HIP(ctx, hipHostMalloc(&ctx->msm_host_pinned, ctx->msm_host_pinned_bytes, hipHostMallocDefault));
+  }
+  {
+    // control block of the bucket fill: zero when idle (the histogram kernel restores that), zeroed when (re)allocated
+    const MsmGeom g1 = make_geom(n, ctx->opt_msm_window_bits, bases->table_c, bases->n, per_piece);
+    if (ctx->msm_ctl_cap < g1.np) {
+      const u32 cap = std::max<u32>(g1.np, 1u << 16);
+      rc = ensure_buffer(ctx, ctx->msm_ctl, sort_ctl_words(cap) * 4);
+      if (rc) return rc;
+      PM_HIP(ctx, hipMemsetAsync(ctx->msm_ctl.ptr, 0, ctx->msm_ctl.bytes, st));
+      ctx->msm_ctl_cap = cap;
+    }
+  }
+  hipStream_t streams[2] = {st, st};
+  if (npieces > 1) {
+    if (!ctx->msm_side) PM_HIP(ctx, hipStreamCreateWithFlags(&ctx->msm_side, hipStreamNonBlocking));
+    streams[1] = ctx->msm_side;
+    while (ctx->msm_events.size() < npieces) {
+      hipEvent_t e = nullptr;
+      PM_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->msm_events.push_back(e);
+    }
+  }
+  std::vector<MsmPiece> pieces(npieces);
+  for (u32 i = 0; i < npieces && rc == PM_OK; ++i) {
+    const u32 first = i * per_piece, cnt = std::min<u32>(per_piece, batch - first);
+    hipStream_t si = streams[i & 1];
+    // piece i starts when piece i - 1 has left the accumulate (and with it everything the caller queued on `st` before
+    // this call: piece 0 runs on `st`); the piece that used this region and this stream before, i - 2, is in order
+    if (i > 0) {
+      hipError_t we = hipStreamWaitEvent(si, ctx->msm_events[i - 1], 0);
+      if (we != hipSuccess) {
+        rc = set_err(ctx, PM_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(we));
+        break;
+      }
+    }
+    size_t dummy_ws = 0, dummy_pin = 0;
+    rc = msm_piece(ctx, bases, offset, n, (const char*)d_scalars + (size_t)first * sc_stride * 32, sc_stride, cnt, scalar_form, si,
+                   npieces > 1 ? ctx->msm_events[i] : nullptr, (char*)ctx->msm_ws.ptr + (size_t)(i & 1) * region, &dummy_ws,
+                   (char*)ctx->msm_host_pinned + (size_t)i * pin_each, &dummy_pin, &pieces[i]);
+  }
+  // whatever was enqueued is waited for, also on an error path: the side stream must be idle when the call returns
+  hipError_t e0 = hipStreamSynchronize(st), e1 = npieces > 1 ? hipStreamSynchronize(ctx->msm_side) : hipSuccess;
+  if (rc) return rc;
+  PM_HIP(ctx, e0);
+  PM_HIP(ctx, e1);
+  std::vector<XYZZ> totals(batch);
+  for (u32 i = 0; i < npieces; ++i) msm_fold(pieces[i], totals.data() + (size_t)i * per_piece);
   write_projective_batch(out_xyz, totals.data(), batch);
   return PM_OK;
 }

@@ -151,6 +151,34 @@ def test_precomputed_window_table(ctx, oracle, c):
     assert np.array_equal(pa.g1_to_affine(bases.msm(eq))[0], oracle.g1_msm(pts, eq, SCALAR_MONTGOMERY, 8))
 
 
+def test_batched_msm_as_pipelined_pieces(ctx, oracle):
+    """Option msm_pipeline = 1 (off by default: it loses, msm.hip): a batch runs as up to four pieces on two streams
+    that alternate between two workspace regions.  Same results as the one-piece path, with and without the table."""
+    import plonk_prototype_amd as pa
+    import torch
+    n, kb = 3000, 5
+    pts, sc = _edge_inputs(oracle, n, 91)
+    scs = np.concatenate([sc] + [oracle.fr_sample(500 + j, n) for j in range(1, kb)])
+    d = torch.from_numpy(np.ascontiguousarray(scs).view(np.int64)).cuda()
+    for table in (False, True):
+        bases = pa.host.Bases(ctx, pts)
+        if table:
+            bases.precompute(13)
+        ref = bases.msm_batch_dev(d.data_ptr(), n, kb)
+        ctx.set_option("msm_pipeline", 1)
+        try:
+            for _ in range(2):
+                got = bases.msm_batch_dev(d.data_ptr(), n, kb)
+                assert np.array_equal(got, ref)
+            assert np.array_equal(bases.msm_batch_dev(d.data_ptr(), n, 2), ref[:2])
+        finally:
+            ctx.set_option("msm_pipeline", 0)
+        for j in range(kb):
+            exp = oracle.g1_msm(pts, scs[j * n:(j + 1) * n], SCALAR_MONTGOMERY, 8)
+            assert np.array_equal(pa.g1_to_affine(ref[j])[0], exp), j
+        bases.free()
+
+
 @pytest.mark.parametrize("table", [False, True])
 def test_batched_commits(ctx, oracle, table):
     """pm_g1_msm_batch_dev: k scalar vectors over one SRS in a single pass == k separate MSMs."""

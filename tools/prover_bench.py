@@ -21,6 +21,8 @@ t0 = time.time()
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
 wide = mode in ("wide", "mixed")
 ctx = pa.Context(0)
+if os.environ.get("PM_MSM_PIPELINE") == "0":       # A/B: batched MSMs as one piece (r02 behaviour)
+    ctx.set_option("msm_pipeline", 0)
 if wide:
     circuit, dw, _ = (pa.synthetic.wide_mixed_circuit if mode == "mixed" else pa.synthetic.wide_circuit)(n, ctx, 1)
     pi = np.zeros((n, 4), np.uint64)
