@@ -5,8 +5,8 @@
 #include <cstring>
 
 #include "context.h"
-#include "field_inv.cuh"
-#include "fields.cuh"
+#include "field_inv.hip.h"
+#include "fields.hip.h"
 
 namespace pm {
 

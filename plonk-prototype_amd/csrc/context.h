@@ -63,7 +63,7 @@ struct pm_ctx {
   std::map<const void*, size_t> big_lds;                // ... and the limit set, where it depends on the call
   // MSM workspaces
   pm::DeviceBuffer msm_ws;
-  pm::DeviceBuffer msm_ctl;                             // control block of the bucket fill (msm_sort.cuh): zero when idle
+  pm::DeviceBuffer msm_ctl;                             // control block of the bucket fill (msm_sort.hip.h): zero when idle
   unsigned msm_ctl_cap = 0;                             // partitions it is laid out for
   hipStream_t msm_side = nullptr;                       // second stream of the piece pipeline of a batched MSM (msm.hip)
   std::vector<hipEvent_t> msm_events;                   // "piece i has left the accumulate"

@@ -1,5 +1,5 @@
 // BLS12-381 G1 group law on the device in XYZZ coordinates (x = X/ZZ, y = Y/ZZZ,
-// ZZ^3 = ZZZ^2), over the carry-free Fp of fields.cuh (14 x 28-bit limbs, R' = 2^392).
+// ZZ^3 = ZZZ^2), over the carry-free Fp of fields.hip.h (14 x 28-bit limbs, R' = 2^392).
 //
 // This is the arithmetic under dusk_bls12_381::multiscalar_mul::msm_variable_base
 // (dusk-bls12_381 0.8, pinned at ref:Cargo.toml:20): bucket += point
@@ -17,7 +17,7 @@
 // the limbs of 0 or of p.  The slow path (doubling, or the identity for P + (-P)) is then
 // taken by the few lanes that need it.
 #pragma once
-#include "fields.cuh"
+#include "fields.hip.h"
 
 namespace pm {
 

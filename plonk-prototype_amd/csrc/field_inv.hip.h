@@ -1,5 +1,5 @@
 // Modular inversion in Fr / Fp by an optimised binary GCD (T. Pornin, "Optimized Binary GCD for Modular Inversion",
-// 2020) in the limb form of fields.cuh -- constant work, no data-dependent branches, so the lanes of a wave stay
+// 2020) in the limb form of fields.hip.h -- constant work, no data-dependent branches, so the lanes of a wave stay
 // together.  x^(m-2) costs 255 (Fr) / 381 (Fp) dependent squarings: ~76 k instructions per Fr inversion and the
 // latency floor of every kernel that needs one (r02: 57 % of the batch-inversion kernel).  Here: ROUNDS =
 // ceil((2 bits(m) - 1) / W) rounds (18 / 28), each W plain binary-GCD steps on (2 W + 2)-bit approximations of a and b
@@ -10,7 +10,7 @@
 // Invariants (integers, y the input): a = y u, b = y v (mod m); start a = y, b = m, u = 1, v = 0; after all rounds
 // a = 0, b = gcd = 1 and v = 1 / y; y = 0 gives v = 0 ("zeros stay zero", util::batch_inversion).
 #pragma once
-#include "fields.cuh"
+#include "fields.hip.h"
 
 namespace pm {
 

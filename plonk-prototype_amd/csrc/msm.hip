@@ -5,7 +5,7 @@
 // by dusk_plonk's CommitKey::commit (ref:Cargo.toml:19).  SURVEY.md CS-4, section 8a a8-a10.
 //
 // Pipeline (all on one stream, no host round trip until the window sums come back):
-//   1 + 2 bucket fill  (msm_sort.cuh) scalar -> canonical integer -> signed c-bit digits; one (key, value) pair per
+//   1 + 2 bucket fill  (msm_sort.hip.h) scalar -> canonical integer -> signed c-bit digits; one (key, value) pair per
 //                     non-zero digit: key = window << (c-1) | (|d| - 1), value = point index | sign << 31;
 //                     the pairs grouped by key with a hand-written partition + local counting sort -> every
 //                     bucket's points are contiguous; the sum is order independent (exact group law)
@@ -17,7 +17,7 @@
 //                     until one thread is left
 //   4 msm_bucket_reduce  per bucket set: sum_b (b+1) B_b by running sums over a few buckets per lane
 //                     pair, a suffix scan and a tree across the wave, and two or three small levels
-//                     of the same shape (every point on two lanes: struct Half in ec.cuh)
+//                     of the same shape (every point on two lanes: struct Half in ec.hip.h)
 //   5 host            2-4 points per bucket set -> the powers of two of the reduction levels, the
 //                     Horner fold with c doublings per window (none with the window table) and
 //                     the final inversion on one CPU core (a serial chain of 20-300 group
@@ -35,10 +35,10 @@
 #include <vector>
 
 #include "context.h"
-#include "ec.cuh"
-#include "field_inv.cuh"
+#include "ec.hip.h"
+#include "field_inv.hip.h"
 #include "host_field.h"
-#include "msm_sort.cuh"
+#include "msm_sort.hip.h"
 
 namespace pm {
 
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(128) precompute_affine_kernel(const u32x4* scr
     for (int k = 0; k < 14; ++k) nz |= ld_fp_limbs(scratch + 16 * i + 8).l[k];
     if (nz) acc = fe_mul<FpP>(acc, zzz);
   }
-  // 1 / acc (binary GCD, field_inv.cuh; r01 / r02: acc^(p-2), 381 dependent squarings per thread)
+  // 1 / acc (binary GCD, field_inv.hip.h; r01 / r02: acc^(p-2), 381 dependent squarings per thread)
   Fp inv = fe_inv_dev<FpP>(acc);
   for (u32 j = per; j-- > 0;) {
     const size_t i = t + (size_t)j * T;
@@ -369,10 +369,10 @@ __global__ void __launch_bounds__(128) msm_accumulate_ln_kernel(const AccArgs a)
 }
 
 // ------------------------------------------------------------------ 4: bucket reduce
-static constexpr u32 GROUP = 32;   // items per wave in the reduction: one per lane PAIR (ec.cuh, struct Half)
+static constexpr u32 GROUP = 32;   // items per wave in the reduction: one per lane PAIR (ec.hip.h, struct Half)
 // sum_b (b + 1) B_b for every bucket set, as a hierarchy of wave-level reductions with NO per-thread scalar
 // multiple (r01 / early r02: each thread finished its chunk with (chunk offset) x (chunk sum)), and with every
-// point held by a PAIR of lanes (struct Half in ec.cuh: 7 field-product rounds per addition instead of 14).
+// point held by a PAIR of lanes (struct Half in ec.hip.h: 7 field-product rounds per addition instead of 14).
 // These kernels run one or two waves per SIMD with long dependent chains, and a lone wave issues one VALU
 // instruction per ~7 cycles: halving the instructions per group operation is what shortens them.
 //   level 1 (msm_bucket_wave_kernel): a lane pair takes `lb` consecutive buckets with the two running sums
@@ -684,7 +684,7 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   u32* ctl = (u32*)ctx->msm_ctl.ptr;
   u32x4* buckets = (u32x4*)(ws + o_buckets);
 
-  // 1 + 2 bucket fill (msm_sort.cuh)
+  // 1 + 2 bucket fill (msm_sort.hip.h)
   {
     u32 tiles_per_wg = 1;   // at most ~2 K workgroups: the partition totals cost one atomic per (workgroup-tile, partition)
     while ((size_t)batch * ((g.tiles + tiles_per_wg - 1) / tiles_per_wg) > 2048) ++tiles_per_wg;

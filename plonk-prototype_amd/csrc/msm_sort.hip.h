@@ -28,7 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/plonk_mi355x.h"
-#include "fields.cuh"
+#include "fields.hip.h"
 
 namespace pm {
 

@@ -12,7 +12,7 @@
 
 #include "context.h"
 #include "host_field.h"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hip.h"
 
 namespace pm {
 

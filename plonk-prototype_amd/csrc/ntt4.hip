@@ -5,7 +5,7 @@
 #include <algorithm>
 
 #include "context.h"
-#include "ntt_kernels4.cuh"
+#include "ntt_kernels4.hip.h"
 
 namespace pm {
 

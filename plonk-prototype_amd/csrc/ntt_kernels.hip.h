@@ -15,7 +15,7 @@
 // straight from HBM, the last one stores straight to HBM, and the steps in between exchange
 // through LDS (limb planes of 16+16+4 bytes so consecutive lanes hit consecutive banks).
 //
-// Number representation (fields.cuh): 9 x 29-bit limbs, lazily reduced.  Between passes the
+// Number representation (fields.hip.h): 9 x 29-bit limbs, lazily reduced.  Between passes the
 // vector lives in HBM in the same 9-limb "wide" form (36 B/element, blocked by 4), so only
 // the first load unpacks canonical data and only the last store canonicalises.
 //
@@ -25,7 +25,7 @@
 // Cost: 13 Montgomery products per radix-8 butterfly (8 twiddles incl. a reducing multiply
 // by one on the untwiddled input, 5 constants); the kernel is integer-ALU bound.
 #pragma once
-#include "fields.cuh"
+#include "fields.hip.h"
 
 namespace pm {
 

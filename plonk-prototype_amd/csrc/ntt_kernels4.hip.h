@@ -1,9 +1,9 @@
-// Radix-4 variant of the Stockham pass kernel (see ntt_kernels.cuh for the algorithm): every
+// Radix-4 variant of the Stockham pass kernel (see ntt_kernels.hip.h for the algorithm): every
 // thread keeps FOUR elements (36 VGPRs of data instead of 72) and a wave owns 9 KiB of the LDS
 // tile instead of 18, so four waves per SIMD fit where the radix-8 kernel is limited to two by
 // LDS.  Same passes, same tables for the inter-pass twiddles, its own step-twiddle tables.
 #pragma once
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hip.h"
 
 namespace pm {
 

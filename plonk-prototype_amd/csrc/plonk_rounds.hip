@@ -11,7 +11,7 @@
 // multiplication (:34,37; ref:src/zk/circuits.rs:64) and variable-base curve addition (:40).  The
 // formulas are restated from the published dusk-plonk 0.8 design (parity unpinned).
 //
-// Scaling bookkeeping (poly_common.cuh): memory holds ABI form (x 2^256); a product of forms 2^a and
+// Scaling bookkeeping (poly_common.hip.h): memory holds ABI form (x 2^256); a product of forms 2^a and
 // 2^b is of form 2^(a+b-261).  Wires are moved to device form (2^261) once per point, challenges are
 // prepared by the host in the form that makes every sum homogeneous, the result leaves in ABI form.
 #include <hip/hip_runtime.h>
@@ -21,8 +21,8 @@
 
 #include "context.h"
 #include "host_field.h"
-#include "ntt_kernels.cuh"
-#include "poly_common.cuh"
+#include "ntt_kernels.hip.h"
+#include "poly_common.hip.h"
 
 namespace pm {
 

@@ -14,10 +14,10 @@
 #include <vector>
 
 #include "context.h"
-#include "field_inv.cuh"
+#include "field_inv.hip.h"
 #include "host_field.h"
-#include "ntt_kernels.cuh"
-#include "poly_common.cuh"
+#include "ntt_kernels.hip.h"
+#include "poly_common.hip.h"
 
 namespace pm {
 
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, size_t n, 
     st_tw(scratch, i, acc);                    // product of the earlier non-zero elements
     if (nz) acc = fe_mul<FrP>(acc, abi_to_dev(raw));
   }
-  // 1 / acc by the binary GCD of field_inv.cuh (~16 k instructions; r01 / r02: acc^(r-2), ~76 k and 57 % of a thread's
+  // 1 / acc by the binary GCD of field_inv.hip.h (~16 k instructions; r01 / r02: acc^(r-2), ~76 k and 57 % of a thread's
   // work).  acc = x R' (device form): the integer inverse is x^-1 / R'; times R R'^2 (and the product's 1 / R') gives
   // x^-1 R, the ABI form the back-substitution wants
   Fr inv = fe_mul<FrP>(fe_inv_int<FrP>(fe_canon_limbs<FrP>(acc)), fe_pow2<FrP, 256 + 2 * 261>());

@@ -5,7 +5,7 @@
 #include <cstring>
 
 #include "host_field.h"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hip.h"
 
 namespace pm {
 

@@ -30,7 +30,7 @@ def test_mul_add_sub(ctx, oracle, field):
 
 @pytest.mark.parametrize("field", ["fr", "fp"])
 def test_inverse(ctx, oracle, field):
-    """The binary-GCD inversion of csrc/field_inv.cuh against pow(x, -1, m): edge values (0 stays 0, 1, m - 1, powers of
+    """The binary-GCD inversion of csrc/field_inv.hip.h against pow(x, -1, m): edge values (0 stays 0, 1, m - 1, powers of
     two, small numbers whose approximations are exact from the first round on) and random ones."""
     mod, nl, op = (B.R_MOD, 4, 6) if field == "fr" else (B.P_MOD, 6, 7)
     rng = B.sample_fr(5 if field == "fr" else 6, 3000)

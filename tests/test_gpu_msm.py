@@ -324,7 +324,7 @@ def test_reduction_meets_equal_and_opposite_sums(ctx, oracle):
     """The bucket reduction adds bucket sums and running sums to each other: with bases drawn from
     {G, -G, 2G, infinity} and tiny scalars, neighbouring buckets, chunks and waves hold EQUAL or OPPOSITE
     points all the time, so the P + P (doubling) and P - P (identity) branches of the two-lane group law
-    (ec.cuh, half_add) run in the running sums, in the suffix scan and in the trees.  Both paths (per-call
+    (ec.hip.h, half_add) run in the running sums, in the suffix scan and in the trees.  Both paths (per-call
     bases and the window table), several chunk sizes."""
     import plonk_prototype_amd as pa
     rng = np.random.default_rng(2024)

@@ -3,7 +3,7 @@
 // random 96-byte rows of a 1.3 GB table of affine points), without any of the bucket bookkeeping, i.e. the most
 // favourable setting for the affine form.
 //
-//   part 1  cost of one Fp inversion (binary GCD, csrc/field_inv.cuh) in units of one Fp product, both as dependent
+//   part 1  cost of one Fp inversion (binary GCD, csrc/field_inv.hip.h) in units of one Fp product, both as dependent
 //           chains at two waves per SIMD
 //   part 2  per pair (P, Q) of table rows:
 //             XYZZ    acc = P; acc += Q                 (one madd: 8 M + 2 S with the merged reduction, r03)
@@ -20,8 +20,8 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../plonk-prototype_amd/csrc/ec.cuh"
-#include "../plonk-prototype_amd/csrc/field_inv.cuh"
+#include "../plonk-prototype_amd/csrc/ec.hip.h"
+#include "../plonk-prototype_amd/csrc/field_inv.hip.h"
 
 using namespace pm;
 #define CK(x)                                                                        \

@@ -1,6 +1,6 @@
 // A/B of two ways to form a BLS12-381 Montgomery product on gfx950:
 //   A  the library's integer product: unsaturated 29/28-bit limbs, one v_mad_u64_u32 per limb
-//      product with a 64-bit column accumulator (csrc/fields.cuh, fe_mul / fe_sqr)
+//      product with a 64-bit column accumulator (csrc/fields.hip.h, fe_mul / fe_sqr)
 //   B  a double-precision-FMA product on 52-bit limbs (Emmart/Zheng/Weems style): each limb
 //      product is split exactly into hi = fma_rz(a, b, 2^104) and lo = fma_rz(a, b, 2^104 + 2^52 - hi),
 //      and the mantissa bit patterns are summed into 64-bit integer columns
@@ -14,7 +14,7 @@
 #include <string.h>
 #include <vector>
 
-#include "fields.cuh"
+#include "fields.hip.h"
 
 using namespace pm;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)

@@ -13,9 +13,14 @@ python tools/pmc_summary.py gpurun_out/$TAG $OUT/pmc_summary.json > $OUT/pmc_sum
 python tools/pmc_summary.py gpurun_out/$TAG $OUT/pmc_prover_summary.json prv_ > $OUT/pmc_prover_summary.txt 2>&1 && \
 timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err && \
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1 && \
+(timeout -k 10 300 ./tools/sort_bench > $OUT/sort_bench.txt 2>&1; true) && \
+(timeout -k 10 300 python tools/poly_rows.py 22 10 > $OUT/poly_rows.txt 2>&1; true) && \
+(timeout -k 10 300 python tools/prover_bench.py 20 7 > $OUT/prover20.txt 2>&1; true) && \
 (cd /tmp && export TMPDIR=/tmp && \
  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/bench.py --steps 200 --no-cpu-baseline --no-msm --no-poly --no-prover --no-ntt-extra > $OUT/stats_headline.json 2> $OUT/stats_headline.err && \
- timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --no-cpu-baseline --msm-large-log-n 0 --no-poly --no-ntt-extra > $OUT/stats_bench.json 2> $OUT/stats.err)
+ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --no-cpu-baseline --msm-large-log-n 0 --no-poly --no-ntt-extra > $OUT/stats_bench.json 2> $OUT/stats.err && \
+ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm -- python3 $R/tools/msm_table_sweep.py 20 20 8 > $OUT/stats_msm.txt 2> $OUT/stats_msm.err && \
+ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm24 -- python3 $R/tools/msm_table_sweep.py 24 22 32 > $OUT/stats_msm24.txt 2> $OUT/stats_msm24.err)
 echo "final rc=$?"
 tail -3 $OUT/pytest_gpu.txt
 cat $OUT/smoke.txt

@@ -1,4 +1,4 @@
-// Stand-alone check + timing of the MSM bucket fill (csrc/msm_sort.cuh): digits -> partitions -> local sort.
+// Stand-alone check + timing of the MSM bucket fill (csrc/msm_sort.hip.h): digits -> partitions -> local sort.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -pragma-unroll-threshold=1000000 tools/sort_bench.hip -o tools/sort_bench
 //   ./tools/sort_bench [quick]
 // Every case is compared with a CPU restatement of the digit rule (same multiset of (key, value) pairs, keys
@@ -13,7 +13,7 @@
 #include <vector>
 
 #define SORT_TIMING 1
-#include "../plonk-prototype_amd/csrc/msm_sort.cuh"
+#include "../plonk-prototype_amd/csrc/msm_sort.hip.h"
 
 using namespace pm;
 
