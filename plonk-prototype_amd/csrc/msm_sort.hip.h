@@ -303,11 +303,33 @@ __global__ void __launch_bounds__(NT) msm_digits_hist_kernel(const u32x4* scalar
     SORT_T(0, 0);
     for (u32 b = tid; b < g.bins; b += NT) lds_hist[b] = 0;
     __syncthreads();
-    for (u32 q0 = 0; q0 < g.ts; q0 += NT) {   // NT threads per tile of g.ts scalars (several workgroups per CU: the
-      const u32 si = q0 + tid;                // loads of one hide behind the arithmetic of the others)
+    // NT threads walk the tile of g.ts scalars in steps of NT; the next step's scalar is requested before the current
+    // one is processed (and several workgroups share a CU: the loads of one hide behind the arithmetic of the others)
+    const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+    u32x4 ra = zero4, rb = zero4;
+    {
+      const size_t i = (size_t)t * g.ts + tid;
+      if (tid < g.ts && i < n) {
+        const u32x4* sp = scalars + 2 * ((size_t)j * sc_stride + i);
+        ra = sp[0];
+        rb = sp[1];
+      }
+    }
+    for (u32 q0 = 0; q0 < g.ts; q0 += NT) {
+      const u32 si = q0 + tid;
       const size_t i = (size_t)t * g.ts + si;
+      const u32 sw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+      {
+        const u32 sn = si + NT;
+        const size_t in = i + NT;
+        if (sn < g.ts && in < n) {
+          const u32x4* sp = scalars + 2 * ((size_t)j * sc_stride + in);
+          ra = sp[0];
+          rb = sp[1];
+        }
+      }
       if (si < g.ts && i < n) {
-        Fr s = fe_load<FrP>(scalars + 2 * ((size_t)j * sc_stride + i));
+        Fr s = fe_unpack<FrP>(sw);
         // Montgomery (x * 2^256): multiply by 2^5 / 2^261 -> x.   Canonical: multiply by one -> x mod r.
         if (scalar_form == PM_SCALAR_MONTGOMERY)
           s = fe_mul_limb<FrP>(s, 32u);
