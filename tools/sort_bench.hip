@@ -64,7 +64,7 @@ struct Case {
   uint32_t c;
   bool table;
   uint32_t batch;
-  int dist;   // 0 uniform, 1 all equal, 2 witness-like, 3 all zero, 4 30 % equal
+  int dist;   // 0 uniform, 1 all equal, 2 witness-like, 3 all zero, 4 30 % equal, 5 long carry runs
   const char* name;
 };
 
@@ -88,6 +88,12 @@ static bool run_case(const Case& cs, int reps, bool full_check) {
     const double u = (double)(rnd() >> 11) / 9007199254740992.0;
     if (cs.dist == 1 || (cs.dist == 4 && u < 0.3)) memcpy(w, eq, 32);
     if (cs.dist == 3) memset(w, 0, 32);
+    if (cs.dist == 5) {   // carries that run to the top: r - 1 - small, 2^254 - 1, a lone power of two
+      static const uint32_t rm1[8] = {0x00000000u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+      if (u < 0.4) { memcpy(w, rm1, 32); w[2] -= (uint32_t)(rnd() & 0xff); }
+      else if (u < 0.7) { for (int q = 0; q < 8; ++q) w[q] = 0xffffffffu; w[7] = 0x3fffffffu; }
+      else { memset(w, 0, 32); const uint32_t b = (uint32_t)(rnd() % 254); w[b >> 5] = 1u << (b & 31); }
+    }
     if (cs.dist == 2) {
       if (u < 0.90) { w[0] &= 0xffffu; for (int q = 1; q < 8; ++q) w[q] = 0; }
       else if (u < 0.95) memset(w, 0, 32);
@@ -239,6 +245,8 @@ int main(int argc, char** argv) {
       {100, 8, false, 1, 0, "n=100 c=8"},
       {1000, 13, true, 1, 0, "n=1000 table c=13"},
       {3000, 4, false, 1, 0, "c=4, 64 windows"},
+      {1000, 13, true, 1, 5, "n=1000 table c=13 carry runs"},
+      {1000, 7, false, 1, 5, "n=1000 c=7 carry runs"},
       {4096, 8, false, 2, 0, "2^12 batch 2"},
       {100, 20, true, 1, 0, "n=100 table c=20"},
       {1 << 15, 13, true, 1, 0, "2^15 table c=13"},
