@@ -274,6 +274,29 @@ def test_full_size_2_24_against_the_discrete_log(ctx, oracle):
     ck._bases.free()
 
 
+def test_2_26_points_against_the_discrete_log(ctx, oracle):
+    """Four times BASELINE's largest MSM: 2^26 points (6.4 GB of SRS, a 77 GB window table, 8 x 10^8 (digit, point)
+    pairs -- 31-bit pair indices and 64-bit byte offsets everywhere).  Everything stays on the device: the key from
+    the fixed-base kernel, uniform scalars from torch, s(tau) from the Horner kernel (no MSM code in it); the host does one
+    scalar multiplication."""
+    import plonk_prototype_amd as pa
+    import torch
+    n = 1 << 26
+    tau = 0x3C6EF372FE94F82BA54FF53A5F1D36F1510E527FADE682D19B05688C2B3E6C1F % B.R_MOD
+    tau_m = oracle.fr_to_mont(ints_to_limbs([tau], 4))[0]
+    ck = pa.CommitKey.setup(n - 1, tau_m, ctx, precompute=True)
+    g = torch.Generator(device="cuda").manual_seed(2626)
+    sc = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc[:, 3] &= 0x3FFFFFFFFFFFFFFF                                  # below 2^254 < r: valid Montgomery residues
+    torch.cuda.synchronize()
+    for m in (n, n - 12345):
+        got, ident = pa.g1_to_affine(ck._bases.msm_dev(sc.data_ptr(), m))
+        s_tau = oracle.fr_from_mont(ctx.fr_evaluate(sc.data_ptr(), m, tau_m).reshape(1, 4))[0]
+        assert not ident and np.array_equal(got, oracle.g1_mul(oracle.g1_generator(), s_tau)), m
+    del sc
+    ck._bases.free()
+
+
 @pytest.mark.parametrize("n", [1, 2, 300, 5000])
 def test_srs_setup_on_the_gpu(ctx, oracle, n):
     """CommitKey.setup: powers_of_g[i] = tau^i G from the fixed-base kernel, against per-point

@@ -185,3 +185,40 @@ def test_host_batch_pipeline_matches_the_serial_path(ctx, oracle, log_n, batch, 
         assert np.array_equal(piped, serial)
         for b in range(batch):
             assert np.array_equal(piped[b], oracle.fr_ntt(a[b], log_n, flags, 4)), (flags, b)
+
+
+@pytest.mark.parametrize("k", [26, 28, 30])
+def test_large_domains_device_resident(ctx, oracle, k):
+    """Domains well above BASELINE's (2^28 x 32 B = 8.6 GB per vector; EvaluationDomain::new allows up to 2^31): three
+    passes, 64-bit element offsets, the two-level twiddle path above 2^26.  Device-resident, checked through
+    size-independent properties: inverse(forward(a)) == a, coset round trip, NTT(a)[j] == a(w^j) with the evaluation done
+    by the (independent) Horner kernel pm_fr_poly_evaluate_dev, ragged input, delta -> ones."""
+    import torch
+    n = 1 << k
+    g = torch.Generator(device="cuda").manual_seed(1234 + k)
+    a = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    a[:, 3] &= 0x3FFFFFFFFFFFFFFF                                  # any value below 2^254 < r is an element
+    out = torch.empty_like(a)
+    ctx.fr_ntt_dev(a.data_ptr(), n, out.data_ptr(), k, 0)
+    w = B.Domain(n).group_gen
+    for j in (0, 1, n // 2 + 12345, n - 1):
+        wj = oracle.fr_to_mont(ints_to_limbs([pow(w, j, B.R_MOD)], 4))[0]
+        got = ctx.fr_evaluate(a.data_ptr(), n, wj)
+        assert np.array_equal(out[j].cpu().numpy().view(np.uint64), got), j
+    ctx.fr_ntt_dev(out.data_ptr(), n, out.data_ptr(), k, INVERSE)   # in place
+    torch.cuda.synchronize()
+    assert torch.equal(out, a)
+    # the prover's shape: n / 4 coefficients onto the coset of size n, and back
+    ctx.fr_ntt_dev(a.data_ptr(), n // 4, out.data_ptr(), k, COSET)
+    pt = oracle.fr_to_mont(ints_to_limbs([7 * pow(w, 3, B.R_MOD) % B.R_MOD], 4))[0]
+    got = ctx.fr_evaluate(a.data_ptr(), n // 4, pt)               # synchronises the context's stream
+    assert np.array_equal(out[3].cpu().numpy().view(np.uint64), got)
+    ctx.fr_ntt_dev(out.data_ptr(), n, out.data_ptr(), k, INVERSE | COSET)
+    torch.cuda.synchronize()
+    assert torch.equal(out[: n // 4], a[: n // 4]) and not bool(out[n // 4:].any())
+    # delta -> all ones (Montgomery one everywhere)
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))
+    d_one = torch.from_numpy(one.view(np.int64)).cuda()
+    ctx.fr_ntt_dev(d_one.data_ptr(), 1, out.data_ptr(), k, 0)
+    torch.cuda.synchronize()
+    assert bool((out == d_one).all())
