@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
   const u32 ntile = (size + SORT_TILE2_PAIRS - 1) / SORT_TILE2_PAIRS;
   const u64* src = pairs + lo;
   if (ntile > 1) {   // streamed partition: bucket counts over the whole partition first
+    SORT_T(2, 6);
     for (u32 b = tid; b < nb; b += SORT_THREADS) cur[b] = 0;
     __syncthreads();
     for (u32 e0 = 0; e0 < size; e0 += SORT_THREADS) {
@@ -549,11 +550,12 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
     }
     __syncthreads();
     (void)block_exclusive_scan(cur, nb, wsum);
+    SORT_T(2, 7);
   }
   for (u32 t = 0; t < ntile; ++t) {
     const u32 base = t * SORT_TILE2_PAIRS;
     const u32 cnt = size - base < SORT_TILE2_PAIRS ? size - base : SORT_TILE2_PAIRS;
-    SORT_T(2, 0);
+    if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 0);   // tools/sort_bench: a full tile
     for (u32 b = tid; b < nb; b += SORT_THREADS) thist[b] = 0;
     u32 lk[SORT_IPT], lv[SORT_IPT];
 #pragma unroll
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
       lv[q] = (u32)pr;
     }
     __syncthreads();
-    SORT_T(2, 1);
+    if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 1);   // tools/sort_bench: a full tile
     u32 rk[SORT_IPT];
     {
       // ranks inside the tile from LDS atomics.  A wave whose pairs ALL carry one bucket (all-equal scalars, a
@@ -603,9 +605,9 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
       }
     }
     __syncthreads();
-    SORT_T(2, 2);
+    if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 2);   // tools/sort_bench: a full tile
     (void)block_exclusive_scan(thist, nb, wsum);
-    SORT_T(2, 3);
+    if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 3);   // tools/sort_bench: a full tile
 #pragma unroll
     for (u32 q = 0; q < SORT_IPT; ++q)
       if (tid + q * SORT_THREADS < cnt) {
@@ -614,7 +616,7 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
         stage_k[pos] = (unsigned short)lk[q];
       }
     __syncthreads();
-    SORT_T(2, 4);
+    if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 4);   // tools/sort_bench: a full tile
     if (ntile == 1) {
       for (u32 e = tid; e < cnt; e += SORT_THREADS) {
         keys_out[lo + e] = key_hi | stage_k[e];
@@ -635,7 +637,7 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     __syncthreads();
-    SORT_T(2, 5);
+    if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 5);   // tools/sort_bench: a full tile
   }
 }
 

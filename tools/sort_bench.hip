@@ -200,9 +200,9 @@ static bool run_case(const Case& cs, int reps, bool full_check) {
   {
     unsigned long long dbg[3][16];
     CK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(sort_dbg), sizeof dbg));
-    printf("      one workgroup, us: scatter [load+reserve %.2f | scan %.2f | stage %.2f | deltas %.2f | copy-out %.2f]  local [load %.2f | rank %.2f | scan %.2f | stage %.2f | copy-out %.2f]\n",
+    printf("      one workgroup, us: scatter [load+reserve %.2f | scan %.2f | stage %.2f | deltas %.2f | copy-out %.2f]  local [count pass %.2f | a full tile: load %.2f | rank %.2f | scan %.2f | stage %.2f | copy-out %.2f]\n",
            (dbg[1][1] - dbg[1][0]) * 0.01, (dbg[1][2] - dbg[1][1]) * 0.01, (dbg[1][3] - dbg[1][2]) * 0.01, (dbg[1][4] - dbg[1][3]) * 0.01,
-           (dbg[1][5] - dbg[1][4]) * 0.01, (dbg[2][1] - dbg[2][0]) * 0.01, (dbg[2][2] - dbg[2][1]) * 0.01, (dbg[2][3] - dbg[2][2]) * 0.01,
+           (dbg[1][5] - dbg[1][4]) * 0.01, (dbg[2][7] - dbg[2][6]) * 0.01, (dbg[2][1] - dbg[2][0]) * 0.01, (dbg[2][2] - dbg[2][1]) * 0.01, (dbg[2][3] - dbg[2][2]) * 0.01,
            (dbg[2][4] - dbg[2][3]) * 0.01, (dbg[2][5] - dbg[2][4]) * 0.01);
     static unsigned long long span[3][4096][2];
     CK(hipMemcpyFromSymbol(span, HIP_SYMBOL(sort_span), sizeof span));
