@@ -87,6 +87,11 @@ void pm_shutdown(pm_ctx* ctx);
 const char* pm_last_error(const pm_ctx* ctx);
 /* Block until everything queued on the context's stream has finished. */
 int pm_sync(pm_ctx* ctx);
+/* Give back what the context caches between calls -- pass buffers, MSM / polynomial workspaces, staging, twiddle tables --
+ * after waiting for the device; everything is rebuilt or regrown on demand (a workspace only ever grows otherwise: after
+ * one 2^30-point transform a context holds 77 GB of pass buffers).  pm_bases and pm_prover_key objects are untouched.
+ * freed_bytes (may be NULL): device memory returned to the driver. */
+int pm_trim(pm_ctx* ctx, size_t* freed_bytes);
 
 /* ---- EvaluationDomain ------------------------------------------------------------------ */
 

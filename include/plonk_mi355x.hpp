@@ -50,6 +50,8 @@ class Context {
   pm_ctx* get() const { return h_; }
   void check(int rc) const { if (rc != PM_OK) throw Error(rc, pm_last_error(h_)); }
   void sync() const { check(pm_sync(h_)); }
+  // release cached workspaces / twiddle tables (regrown on demand); returns the bytes given back
+  size_t trim() const { size_t f = 0; check(pm_trim(h_, &f)); return f; }
 
  private:
   pm_ctx* h_ = nullptr;

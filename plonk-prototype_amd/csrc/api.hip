@@ -134,11 +134,8 @@ extern "C" int pm_init(int device_id, pm_ctx** out) {
   return PM_OK;
 }
 
-extern "C" void pm_shutdown(pm_ctx* ctx) {
-  if (!ctx) return;
-  (void)pm_comm_destroy(ctx);
-  (void)hipSetDevice(ctx->device);
-  (void)hipDeviceSynchronize();
+// Twiddle caches and workspaces: everything a context rebuilds or regrows on demand.  The device must be idle.
+static void release_caches(pm_ctx* ctx, bool all) {
   for (int d = 0; d < 2; ++d) {
     for (auto& kv : ctx->step_tw[d]) (void)hipFree(kv.second);
     for (auto& kv : ctx->step4_tw[d]) (void)hipFree(kv.second);
@@ -149,10 +146,38 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
       (void)hipFree(kv.second.cs_lo);
       for (void* t : kv.second.pass_tw) (void)hipFree(t);
     }
+    ctx->step_tw[d].clear();
+    ctx->step4_tw[d].clear();
+    ctx->domain[d].clear();
   }
-  for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws, &ctx->msm_ctl,
-                          &ctx->msm_scalars, &ctx->poly_ws, &ctx->poly_tab})
+  for (DeviceBuffer* b : {&ctx->ntt_tmp[0], &ctx->ntt_tmp[1], &ctx->io_in, &ctx->io_out, &ctx->msm_ws, &ctx->msm_scalars,
+                          &ctx->poly_ws, &ctx->poly_tab}) {
     if (b->ptr) (void)hipFree(b->ptr);
+    b->ptr = nullptr;
+    b->bytes = 0;
+  }
+  if (all && ctx->msm_ctl.ptr) (void)hipFree(ctx->msm_ctl.ptr);   // pm_trim keeps it: small, and zero-when-idle is its invariant
+}
+
+extern "C" int pm_trim(pm_ctx* ctx, size_t* freed_bytes) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  PM_HIP(ctx, hipDeviceSynchronize());   // the buffers may be in use on any caller stream
+  size_t free0 = 0, free1 = 0, total = 0;
+  PM_HIP(ctx, hipMemGetInfo(&free0, &total));
+  release_caches(ctx, false);
+  PM_HIP(ctx, hipMemGetInfo(&free1, &total));
+  if (freed_bytes) *freed_bytes = free1 > free0 ? free1 - free0 : 0;
+  return PM_OK;
+}
+
+extern "C" void pm_shutdown(pm_ctx* ctx) {
+  if (!ctx) return;
+  (void)pm_comm_destroy(ctx);
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  release_caches(ctx, true);
   if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
   if (ctx->msm_side) (void)hipStreamDestroy(ctx->msm_side);
   for (hipEvent_t e : ctx->msm_events) (void)hipEventDestroy(e);

@@ -72,6 +72,12 @@ class Context:
     def sync(self):
         self._check(self._lib.pm_sync(self._h))
 
+    def trim(self) -> int:
+        """``pm_trim``: release the cached workspaces and twiddle tables (regrown on demand) -> bytes freed."""
+        freed = C.c_size_t(0)
+        self._check(self._lib.pm_trim(self._h, C.byref(freed)))
+        return freed.value
+
     def set_option(self, key: str, value: int):
         self._check(self._lib.pm_set_option(self._h, key.encode(), int(value)))
 

@@ -199,6 +199,7 @@ def test_large_domains_device_resident(ctx, oracle, k):
     a = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
     a[:, 3] &= 0x3FFFFFFFFFFFFFFF                                  # any value below 2^254 < r is an element
     out = torch.empty_like(a)
+    torch.cuda.synchronize()                                       # torch filled `a` on ITS stream; the library uses its own
     ctx.fr_ntt_dev(a.data_ptr(), n, out.data_ptr(), k, 0)
     w = B.Domain(n).group_gen
     for j in (0, 1, n // 2 + 12345, n - 1):
@@ -222,3 +223,6 @@ def test_large_domains_device_resident(ctx, oracle, k):
     ctx.fr_ntt_dev(d_one.data_ptr(), 1, out.data_ptr(), k, 0)
     torch.cuda.synchronize()
     assert bool((out == d_one).all())
+    del a, out
+    torch.cuda.empty_cache()
+    assert ctx.trim() >= 2 * n * 36                                # the two pass buffers at least; the shared context stays small
