@@ -408,6 +408,13 @@ int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap);
  * n elements. */
 int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                      size_t n);
+/* Pure host, no context: the bucket-fill layout (csrc/msm_sort.hip.h) an MSM of this shape would run with -- out[16] =
+ * {window bits, windows, bucket sets, bucket bits, partition bits, local bits, partitions per set, bins, partitions,
+ * scalars per scatter tile, tiles, LDS bytes scatter, LDS bytes local sort, finer low partitions, their extra bits, 0} --
+ * and, when the three arrays are given (2^bucket-bits / partitions-per-set entries), the partition of every bucket and
+ * every partition's first bucket and log2 width.  table_window_bits 0 = bases without a window table. */
+int pm_test_msm_geometry(size_t n, long window_bits, uint32_t table_window_bits, uint32_t batch, uint32_t out[16],
+                         uint32_t* part_of_bucket, uint32_t* first_bucket, uint32_t* width_bits);
 
 #ifdef __cplusplus
 }

@@ -1074,6 +1074,24 @@ extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t win
 
 extern "C" size_t pm_g1_bases_len(const pm_bases* bases) { return bases ? bases->n : 0; }
 
+// test hook (pure host): the bucket-fill layout the library would use for an MSM of this shape, and its bucket ->
+// partition map.  out[16]: c, windows, bucket sets, bucket bits, partition bits, local bits, partitions per set, bins,
+// partitions, scalars per scatter tile, tiles, LDS bytes of the scatter kernel, of the local sort, finer low partitions
+// (count, extra bits), 0.  part_of_bucket / first_bucket / width_bits (each n_buckets_out entries, may be NULL): the
+// partition of every bucket of one set, and for every partition its first bucket and log2 of its bucket count.
+extern "C" int pm_test_msm_geometry(size_t n, long window_bits, uint32_t table_window_bits, uint32_t batch, uint32_t out[16],
+                                    uint32_t* part_of_bucket, uint32_t* first_bucket, uint32_t* width_bits) {
+  if (!out || !n || !batch) return PM_ERR_BAD_ARG;
+  const MsmGeom g = make_geom(n, window_bits, table_window_bits, table_window_bits ? n : 0, batch);
+  const uint32_t v[16] = {g.c, g.nwin, g.nsets, g.bbits, g.pbits, g.rbits, g.pps, g.bins, g.np, g.ts, g.tiles,
+                          (uint32_t)sort_scatter_lds(g), (uint32_t)sort_local_lds(g), g.na, g.sa, 0};
+  memcpy(out, v, sizeof v);
+  if (part_of_bucket)
+    for (u32 b = 0; b < g.nbuckets; ++b) part_of_bucket[b] = part_of(g, b);
+  for (u32 p = 0; p < g.pps && first_bucket && width_bits; ++p) part_range(g, p, first_bucket[p], width_bits[p]);
+  return PM_OK;
+}
+
 extern "C" int pm_g1_msm_dev(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n,
                              const void* d_scalars, uint32_t scalar_form, uint64_t out_xyz[18],
                              void* hip_stream) {

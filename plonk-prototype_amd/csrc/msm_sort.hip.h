@@ -156,10 +156,10 @@ __device__ unsigned long long sort_span[3][4096][2];   // [kernel][workgroup]: f
 #endif
 
 // partition of a bucket inside its set, and back: first bucket and bucket-index bits of a partition
-PM_DEV u32 part_of(const MsmGeom& g, u32 bucket) {
+__host__ __device__ inline u32 part_of(const MsmGeom& g, u32 bucket) {
   return bucket < g.a_size ? bucket >> (g.rbits - g.sa) : g.na_off + (bucket >> g.rbits);
 }
-PM_DEV void part_range(const MsmGeom& g, u32 pl, u32& first_bucket, u32& bits) {
+__host__ __device__ inline void part_range(const MsmGeom& g, u32 pl, u32& first_bucket, u32& bits) {
   if (pl < g.na) {
     bits = g.rbits - g.sa;
     first_bucket = pl << bits;
