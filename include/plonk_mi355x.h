@@ -413,6 +413,11 @@ int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, 
  * scalars per scatter tile, tiles, LDS bytes scatter, LDS bytes local sort, finer low partitions, their extra bits, 0} --
  * and, when the three arrays are given (2^bucket-bits / partitions-per-set entries), the partition of every bucket and
  * every partition's first bucket and log2 width.  table_window_bits 0 = bases without a window table. */
+/* Pure host, no context: the pass plan of a transform of 2^log_n points (tunables 0 = a fresh context's defaults) --
+ * out[20] = {passes, 4 x {log2 radix, log2 columns per tile, threads per workgroup, LDS bytes}, mask of passes that have
+ * a kernel, log2 group size of the blocked intermediate layout, 0}. */
+int pm_test_ntt_plan(uint32_t log_n, uint32_t batch, long tile_log, long max_radix, long radix, uint32_t num_cus,
+                     uint32_t out[20]);
 int pm_test_msm_geometry(size_t n, long window_bits, uint32_t table_window_bits, uint32_t batch, uint32_t out[16],
                          uint32_t* part_of_bucket, uint32_t* first_bucket, uint32_t* width_bits);
 

@@ -68,6 +68,7 @@ static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10, int radi
   }
   p.npass = (int)((log_n + max_radix - 1) / max_radix);
   p.npass = std::min(p.npass, (int)log_n / 5);  // multi-pass kernels exist for radix >= 2^5
+  p.npass = std::min(p.npass, 4);               // ... and a plan holds four passes (ntt_max_radix 6 or 7 above 2^24 / 2^28)
   int base = (int)log_n / p.npass, extra = (int)log_n % p.npass;
   for (int i = 0; i < p.npass; ++i) {
     p.S[i] = base + (i < extra ? 1 : 0);
@@ -413,6 +414,32 @@ extern "C" int pm_domain_info(uint32_t log_n, uint64_t group_gen[4], uint64_t gr
   memcpy(group_gen, g.l, 32);
   memcpy(group_gen_inv, gi.l, 32);
   memcpy(size_inv, si.l, 32);
+  return PM_OK;
+}
+
+// test hook (pure host): the pass plan ntt_run() follows for this size and these tunables (0 = the defaults of a fresh
+// context).  out[20]: passes, then per pass (up to 4) {log2 radix S, log2 columns per tile LT, threads per workgroup,
+// LDS bytes}, then a bit mask of the passes that have a kernel, then the blocked layout's log2 group size, 0.
+extern "C" int pm_test_ntt_plan(uint32_t log_n, uint32_t batch, long tile_log, long max_radix, long radix, uint32_t num_cus,
+                                uint32_t out[20]) {
+  if (!out || !batch) return PM_ERR_BAD_ARG;
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  const long rdx = radix ? radix : 4;
+  Plan plan = make_plan(log_n, (int)tile_log, (int)(max_radix ? max_radix : 10), (int)rdx, num_cus ? num_cus : 256u, batch);
+  memset(out, 0, 20 * sizeof(uint32_t));
+  out[0] = (uint32_t)plan.npass;
+  for (int i = 0; i < plan.npass; ++i) {
+    const bool last = (i == plan.npass - 1);
+    const int role = plan.npass == 1 ? ROLE_SINGLE : (i == 0 ? ROLE_FIRST : (last ? ROLE_LAST : ROLE_MIDDLE));
+    const int S = plan.S[i], LT = plan.LT[i];
+    const bool r4 = rdx == 4 && find_pass4(S, LT, role) != nullptr;
+    out[1 + 4 * i] = (uint32_t)S;
+    out[2 + 4 * i] = (uint32_t)LT;
+    out[3 + 4 * i] = r4 ? pass4_threads(S, LT) : std::max(64u, (1u << (S + LT)) / 8);
+    out[4 + 4 * i] = (uint32_t)(r4 ? pass4_lds(S, LT) : pass_lds_bytes(S, LT));
+    if ((r4 ? find_pass4(S, LT, role) : find_pass(S, LT, role)) != nullptr) out[17] |= 1u << i;
+  }
+  out[18] = plan.npass ? plan_wide_glog(plan) : 0u;
   return PM_OK;
 }
 

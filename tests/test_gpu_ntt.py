@@ -53,6 +53,32 @@ def test_plan_options(ctx, oracle, k, tile, maxr, radix):
         ctx.set_option("ntt_radix", 4)
 
 
+@pytest.mark.parametrize("k,maxr", [(25, 6), (26, 6), (29, 7)])
+def test_four_pass_plans(ctx, k, maxr):
+    """ntt_max_radix 6 / 7 on large domains would ask for five or six passes; a plan holds four (the CPU test of the plan
+    hook found the overrun).  The four-pass plan and the default three-pass plan give the same bits, both directions."""
+    import torch
+    n = 1 << k
+    g = torch.Generator(device="cuda").manual_seed(77 + k)
+    a = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    a[:, 3] &= 0x3FFFFFFFFFFFFFFF
+    ref, out = torch.empty_like(a), torch.empty_like(a)
+    torch.cuda.synchronize()
+    try:
+        for flags in (0, INVERSE | COSET):
+            ctx.fr_ntt_dev(a.data_ptr(), n, ref.data_ptr(), k, flags)
+            ctx.set_option("ntt_max_radix", maxr)
+            ctx.fr_ntt_dev(a.data_ptr(), n, out.data_ptr(), k, flags)
+            ctx.set_option("ntt_max_radix", 10)
+            ctx.sync()
+            assert torch.equal(ref, out), flags
+    finally:
+        ctx.set_option("ntt_max_radix", 10)
+        del a, ref, out
+        torch.cuda.empty_cache()
+        ctx.trim()
+
+
 def test_xcd_mapping_is_result_neutral(ctx, oracle):
     """blockIdx -> tile placement is a speed knob only."""
     a = oracle.fr_sample(5, 1 << 16)
