@@ -413,6 +413,10 @@ int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, 
  * scalars per scatter tile, tiles, LDS bytes scatter, LDS bytes local sort, finer low partitions, their extra bits, 0} --
  * and, when the three arrays are given (2^bucket-bits / partitions-per-set entries), the partition of every bucket and
  * every partition's first bucket and log2 width.  table_window_bits 0 = bases without a window table. */
+/* Pure host, no device: the library's sizing pass for one MSM piece of this shape -- out[4] = {its return code, device
+ * workspace bytes, pinned host bytes, (digit, point) pairs at most}. */
+int pm_test_msm_sizing(size_t n, uint32_t batch, long window_bits, uint32_t table_window_bits, uint32_t num_cus,
+                       uint64_t out[4]);
 /* Pure host, no context: the pass plan of a transform of 2^log_n points (tunables 0 = a fresh context's defaults) --
  * out[20] = {passes, 4 x {log2 radix, log2 columns per tile, threads per workgroup, LDS bytes}, mask of passes that have
  * a kernel, log2 group size of the blocked intermediate layout, 0}. */

@@ -121,6 +121,7 @@ SIGNATURES = {
     "pm_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "pm_test_field_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
     "pm_test_ntt_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_long, C.c_long, C.c_long, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "pm_test_msm_sizing": (C.c_int, [C.c_size_t, C.c_uint32, C.c_long, C.c_uint32, C.c_uint32, u64p]),
     "pm_test_msm_geometry": (C.c_int, [C.c_size_t, C.c_long, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }

@@ -1074,6 +1074,29 @@ extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t win
 
 extern "C" size_t pm_g1_bases_len(const pm_bases* bases) { return bases ? bases->n : 0; }
 
+// test hook (pure host): what one piece of an MSM call of this shape would take -- the library's own sizing pass, on a
+// context that never touches a device.  out[4]: return code of the sizing pass, device workspace bytes, pinned host bytes,
+// (digit, point) pairs at most.
+extern "C" int pm_test_msm_sizing(size_t n, uint32_t batch, long window_bits, uint32_t table_window_bits, uint32_t num_cus,
+                                  uint64_t out[4]) {
+  if (!out || !batch) return PM_ERR_BAD_ARG;
+  pm_ctx ctx;
+  ctx.num_cus = num_cus ? (int)num_cus : 256;
+  ctx.opt_msm_window_bits = window_bits;
+  pm_bases bases;
+  bases.n = n;
+  bases.table_c = table_window_bits;
+  size_t need_ws = 0, need_pin = 0;
+  const int rc = n ? msm_piece(&ctx, &bases, 0, n, nullptr, n, batch, PM_SCALAR_MONTGOMERY, nullptr, nullptr, nullptr, &need_ws,
+                               nullptr, &need_pin, nullptr)
+                   : PM_OK;
+  out[0] = (uint64_t)(int64_t)rc;
+  out[1] = need_ws;
+  out[2] = need_pin;
+  out[3] = n ? (uint64_t)n * batch * make_geom(n, window_bits, table_window_bits, table_window_bits ? n : 0, batch).nwin : 0;
+  return PM_OK;
+}
+
 // test hook (pure host): the bucket-fill layout the library would use for an MSM of this shape, and its bucket ->
 // partition map.  out[16]: c, windows, bucket sets, bucket bits, partition bits, local bits, partitions per set, bins,
 // partitions, scalars per scatter tile, tiles, LDS bytes of the scatter kernel, of the local sort, finer low partitions

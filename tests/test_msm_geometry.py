@@ -92,3 +92,39 @@ def test_low_buckets_of_a_short_top_window_get_finer_partitions(lib, n, table_c)
     assert per_part.mean() * n <= TILE2_PAIRS or n >= 1 << 22                     # single-tile partitions up to 2^20
     if g["sa"]:
         assert np.all(width[: g["na"]] == g["rbits"] - g["sa"]) and np.all(width[g["na"]:] == g["rbits"])
+
+
+def _sizing(lib, n, batch=1, c=0, table_c=0, cus=0):
+    out = (C.c_uint64 * 4)()
+    assert lib.pm_test_msm_sizing(n, batch, c, table_c, cus, out) == 0
+    return C.c_int64(out[0]).value, int(out[1]), int(out[2]), int(out[3])
+
+
+def test_sizing_pass_accepts_every_shape_and_stays_proportionate(lib):
+    """The library's own sizing pass (msm_piece without a workspace), on a context that never touches a device: every
+    shape up to 2^27 points is accepted, the workspace is what the layout says -- pairs three times over (partitioned,
+    sorted keys, sorted values) plus 32 B of integer scalar per point, 256 B per bucket, the partial lists -- and grows
+    with n (without a table the width follows n)."""
+    n_checked = 0
+    for table_c in [0] + list(range(8, 25)):
+        for batch in (1, 2, 4, 15):
+            prev = 0
+            for n in sorted({(1 << k) + d for k in (0, 1, 5, 10, 13, 16, 17, 20, 22, 24, 26, 27) for d in (0, 7)}):
+                if True:
+                    g = _geom(lib, n, 0, table_c, batch)
+                    if g["bins"] > MAX_BINS or g["rbits"] > MAX_RBITS:
+                        assert _sizing(lib, n, batch, 0, table_c)[0] == -1, (n, batch, table_c)   # refused, not launched
+                        continue
+                    rc, ws, pinned, pairs = _sizing(lib, n, batch, 0, table_c)
+                    tag = (n, batch, table_c, rc, ws, pinned, pairs)
+                    assert rc == 0 and pairs == n * batch * g["nwin"], tag
+                    buckets = batch * g["nsets"] << g["bbits"]
+                    assert 16 * pairs + 256 * buckets <= ws <= 21 * pairs + 32 * n * batch + 300 * buckets + (64 << 20), tag
+                    assert 256 * batch * g["nsets"] <= pinned <= 5 * 256 * batch * g["nsets"], tag
+                    assert ws >= 0.9 * prev or not table_c, tag        # (the chunk length steps with the grid's rounds)
+                    prev = ws
+                    n_checked += 1
+    assert n_checked > 1500
+    # fewer CUs (a partitioned device): still accepted, same pair count
+    assert _sizing(lib, 1 << 20, 4, 0, 20, 64)[0] == 0
+    assert _sizing(lib, 0)[0:2] == (0, 0)
