@@ -609,8 +609,13 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   const size_t slots = (size_t)ctx->num_cus * 4 * 2 * 64;
   const size_t want = std::max<size_t>(128, 4 * avg_run);
   const size_t rounds = std::max<size_t>(1, (m + slots * want - 1) / (slots * want));
+  // Small inputs (the commit rounds of a 2^10 .. 2^14-gate circuit) fill a fraction of one round and the kernel's time is
+  // the length of one thread's chain: the chunk goes down to 12 entries, and to 4 where the runs are that short -- below
+  // ~0.6 of a run the in-wave join pays for what the chain saves (profiles/r03_small_msm.txt: batch of four at 2^14,
+  // accumulate 434 -> 365 us; at 2^10, 185 -> 108 us)
+  const u32 chunk_lo = (u32)std::min<size_t>(12, std::max<size_t>(4, (6 * avg_run + 9) / 10));
   const u32 L1 = ctx->opt_msm_chunk ? (u32)ctx->opt_msm_chunk
-                                    : (u32)std::max<size_t>(16, (m + rounds * slots - 1) / (rounds * slots));
+                                    : (u32)std::max<size_t>(chunk_lo, (m + rounds * slots - 1) / (rounds * slots));
   // Partial lists: every level leaves two slots per WAVE; the deeper levels take one slot per lane, so
   // the list shrinks by 32 per level and ends in a single wave (final level).
   struct Level {
@@ -704,7 +709,7 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
       ProfScope prof(ctx, st, "msm_digits");
       hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS0>, dim3(batch * wgs_per_msm), dim3(SORT_THREADS0), (size_t)g.bins * 4, st,
                          (const u32x4*)d_scalars, n, sc_stride, scalar_form, g, tiles_per_wg, wgs_per_msm, (u32)l1_threads,
-                         ctx->opt_msm_chunk ? L1 : 16u, ctl, (u32x4*)(ws + o_canon), (unsigned short*)(ws + o_rows));
+                         ctx->opt_msm_chunk ? L1 : chunk_lo, ctl, (u32x4*)(ws + o_canon), (unsigned short*)(ws + o_rows));
       MSM_STAGE(ctx, st, "digits histogram");
       hipLaunchKernelGGL(msm_digits_scatter_kernel<SORT_THREADS1>, dim3(std::min<u32>(batch * g.tiles, (u32)ctx->num_cus)),
                          dim3(SORT_THREADS1), lds1, st, (const u32x4*)(ws + o_canon), (const unsigned short*)(ws + o_rows), n, g,
