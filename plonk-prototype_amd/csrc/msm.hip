@@ -409,7 +409,9 @@ __global__ void __launch_bounds__(64, 2) msm_bucket_wave_kernel(const u32x4* buc
     if (pi + d < GROUP) running = half_add(running, o, isB);
   }
   if (pi == 0) {
-    st_half(out_w, blockIdx.x, running, isB);
+    Half wsum = running;
+    if (finalize && !wsum.inf) wsum.c0 = fe_mul<FpP>(wsum.c0, fe_one<FpP>());
+    st_half(out_w, blockIdx.x, wsum, isB);
     running = half_identity();
   }
   for (u32 k = 0; k < log_lb; ++k) running = half_double(running, isB);
@@ -460,7 +462,9 @@ __global__ void __launch_bounds__(64, 2) msm_level_kernel(const LevelArgs a) {
       if (pi + d < GROUP) acc = half_add(acc, o, isB);
     }
     if (pi == 0) {
-      st_half(a.w_out, blockIdx.x, acc, isB);
+      Half wsum = acc;
+      if (a.finalize && !wsum.inf) wsum.c0 = fe_mul<FpP>(wsum.c0, fe_one<FpP>());
+      st_half(a.w_out, blockIdx.x, wsum, isB);
       acc = half_identity();
     }
   }
@@ -581,10 +585,10 @@ static bool msm_debug() {
 
 // What the host needs to finish one piece of an MSM call (a sub-batch that went through the kernels on its own).
 struct MsmPiece {
-  u32 batch, nsets, c, n_levels, log_lb, nsets_all;
-  const u32* hw;        // pinned host memory: (n_levels + 1) x nsets_all XYZZ records
+  u32 batch, nsets, c, n_dev, host_items, log_lb, nsets_all;
+  const u32* hw;        // pinned host memory: (n_dev + 2) sequences x nsets_all x host_items XYZZ records
 };
-// One piece: every kernel of the pipeline plus the copy of its (n_levels + 1) x nsets_all result points, enqueued on
+// One piece: every kernel of the pipeline plus the copy of its (n_dev + 2) x nsets_all x host_items result points, enqueued on
 // `st` -- no host synchronisation.  ws == nullptr: nothing is launched, only *need_ws / *need_pinned are set (bytes of
 // device workspace and of pinned host memory a piece of this shape takes).  front_done (optional) is recorded after the
 // last accumulate level: from there on the piece only reads its own buckets (not the control block of the bucket fill).
@@ -647,13 +651,18 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   const u32 chunks_per_win = g.nbuckets / LB;
   // waves per set in level 1, then the group counts of the follow-up levels (64 items per wave) down to one
   const u32 n1 = (chunks_per_win + GROUP - 1) / GROUP;
+  // ... down to at most HOST_ITEMS per set: a launch that folds two or three items is a ~55 us chain of ten dependent
+  // operations on one wave, the same fold is a handful of additions (~1 us each) in the host fold below
+  constexpr u32 HOST_ITEMS = 4;
   std::vector<u32> lvl_groups;
-  for (u32 items = n1; items > 1;) {
-    items = (items + GROUP - 1) / GROUP;
-    lvl_groups.push_back(items);
+  u32 host_items = n1;
+  while (host_items > HOST_ITEMS) {
+    host_items = (host_items + GROUP - 1) / GROUP;
+    lvl_groups.push_back(host_items);
   }
-  const u32 n_levels = (u32)lvl_groups.size();   // follow-up launches; the host receives n_levels + 1 points per set
-  if (n_levels > 3) return set_err(ctx, PM_ERR_BAD_ARG, "internal: bucket reduction deeper than four levels");
+  const u32 n_dev = (u32)lvl_groups.size();   // follow-up launches
+  if (n_dev > 3) return set_err(ctx, PM_ERR_BAD_ARG, "internal: bucket reduction deeper than four levels");
+  // what the host receives: n_dev + 2 sequences (a, the v of every device level, W) of host_items entries per set
 
   // workspace layout
   size_t off = 0;
@@ -675,10 +684,10 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   // level 1 writes (a, W) per wave; level k writes its plain sums, v and W per group; the last level's plain sums
   // and v go to the slots of o_win (slot j: one point per set, nsets_all points per slot) that the host reads
   const size_t o_l1a = take((size_t)nsets_all * n1 * 256), o_l1w = take((size_t)nsets_all * n1 * 256);
-  std::vector<size_t> o_lvl(n_levels);
-  for (u32 k = 0; k < n_levels; ++k) o_lvl[k] = take((size_t)(k + 3) * nsets_all * lvl_groups[k] * 256);
-  const size_t o_win = take((size_t)(n_levels + 1) * nsets_all * 256);
-  const size_t pinned_bytes = (size_t)(n_levels + 1) * nsets_all * 256;
+  std::vector<size_t> o_lvl(n_dev);
+  for (u32 k = 0; k < n_dev; ++k) o_lvl[k] = take((size_t)(k + 3) * nsets_all * lvl_groups[k] * 256);
+  const size_t o_win = take((size_t)(n_dev + 2) * nsets_all * host_items * 256);
+  const size_t pinned_bytes = (size_t)(n_dev + 2) * nsets_all * host_items * 256;
   if (!ws) {
     *need_ws = off;
     *need_pinned = pinned_bytes;
@@ -771,22 +780,22 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   if (front_done) PM_HIP(ctx, hipEventRecord(front_done, st));
   // 4 bucket reduce: level 1 over the buckets, then the small levels (see msm_bucket_wave_kernel)
   u32x4* win = (u32x4*)(ws + o_win);
-  const size_t slot = (size_t)nsets_all * 16;   // u32x4 per slot of o_win
+  const size_t slot = (size_t)nsets_all * host_items * 16;   // u32x4 per sequence in o_win
   {
     ProfScope prof(ctx, st, "msm_bucket_chunk");
     hipLaunchKernelGGL(msm_bucket_wave_kernel, dim3(nsets_all * n1), dim3(64), 0, st, (const u32x4*)buckets, g.nbuckets, LB,
-                       log_lb, n1, n_levels == 0 ? 1u : 0u, n_levels == 0 ? win : (u32x4*)(ws + o_l1a),
-                       (u32x4*)(ws + o_l1w));
+                       log_lb, n1, n_dev == 0 ? 1u : 0u, n_dev == 0 ? win : (u32x4*)(ws + o_l1a),
+                       n_dev == 0 ? win + slot : (u32x4*)(ws + o_l1w));
   }
   PM_HIP(ctx, hipGetLastError());
-  if (n_levels) {
+  if (n_dev) {
     ProfScope prof(ctx, st, "msm_window_sum");
     const u32x4* plain[3] = {(const u32x4*)(ws + o_l1a), nullptr, nullptr};
     const u32x4* w_in = (const u32x4*)(ws + o_l1w);
     u32 items = n1;
-    for (u32 k = 0; k < n_levels; ++k) {
+    for (u32 k = 0; k < n_dev; ++k) {
       const u32 groups = lvl_groups[k], n_plain = k + 1;
-      const bool last = k + 1 == n_levels;
+      const bool last = k + 1 == n_dev;   // writes the host's sequences: [sequence][set x host_items], fit for conversion
       const size_t per = (size_t)nsets_all * groups * 16;   // u32x4 per output array of this level
       u32x4* base = (u32x4*)(ws + o_lvl[k]);
       LevelArgs la;
@@ -797,7 +806,7 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
       la.plain_out0 = pout[0]; la.plain_out1 = pout[1]; la.plain_out2 = pout[2];
       la.w_in = w_in;
       la.v_out = last ? win + n_plain * slot : base + n_plain * per;
-      la.w_out = base + (n_plain + 1) * per;
+      la.w_out = last ? win + (n_plain + 1) * slot : base + (n_plain + 1) * per;
       la.n_plain = n_plain;
       la.n_items = items;
       la.n_groups = groups;
@@ -814,21 +823,41 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   piece->batch = batch;
   piece->nsets = g.nsets;
   piece->c = g.c;
-  piece->n_levels = n_levels;
+  piece->n_dev = n_dev;
+  piece->host_items = host_items;
   piece->log_lb = log_lb;
   piece->nsets_all = nsets_all;
   piece->hw = (const u32*)pinned;
   return PM_OK;
 }
-// 5 host fold of a piece whose copy has arrived: per set F_0 + 32 LB (F_1 + 32 (F_2 + 32 F_3)), then the windows
+// 5 host fold of a piece whose copy has arrived.  Per set the device left n_dev + 2 sequences of host_items entries: the
+// plain sums a, v_1 .. v_ndev and the last W.  The host does the last level itself when host_items > 1 (F_j = the sum of
+// sequence j, one more F = sum_l l W_l), then F_0 + 32 LB (F_1 + 32 (F_2 + 32 F_3)), then the windows.
 static void msm_fold(const MsmPiece& pc, XYZZ* totals) {
   const u32* hw = pc.hw;
+  auto entry = [&](u32 seq, size_t set, u32 item) {
+    return xyzz_to_host(hw + 64 * (((size_t)seq * pc.nsets_all + set) * pc.host_items + item));
+  };
   auto set_total = [&](size_t set) {
-    XYZZ acc = xyzz_to_host(hw + 64 * ((size_t)pc.n_levels * pc.nsets_all + set));
-    for (u32 k = pc.n_levels; k-- > 0;) {
+    XYZZ F[5];
+    u32 L = pc.n_dev;   // F_0 .. F_L
+    for (u32 j = 0; j <= pc.n_dev; ++j) {
+      F[j] = entry(j, set, 0);
+      for (u32 l = 1; l < pc.host_items; ++l) F[j] = host::xyzz_add(F[j], entry(j, set, l));
+    }
+    if (pc.host_items > 1) {   // sum_l l W_l as the sum of the suffix sums from l = 1
+      XYZZ suffix = host::xyzz_identity(), v = host::xyzz_identity();
+      for (u32 l = pc.host_items; l-- > 1;) {
+        suffix = host::xyzz_add(suffix, entry(pc.n_dev + 1, set, l));
+        v = host::xyzz_add(v, suffix);
+      }
+      F[++L] = v;
+    }
+    XYZZ acc = F[L];
+    for (u32 k = L; k-- > 0;) {
       const u32 dbl = k == 0 ? 5 + pc.log_lb : 5;   // log2(GROUP) per level
       for (u32 d = 0; d < dbl; ++d) acc = host::xyzz_double(acc);
-      acc = host::xyzz_add(acc, xyzz_to_host(hw + 64 * ((size_t)k * pc.nsets_all + set)));
+      acc = host::xyzz_add(acc, F[k]);
     }
     return acc;
   };
