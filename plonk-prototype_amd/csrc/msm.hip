@@ -388,6 +388,7 @@ static constexpr u32 GROUP = 32;   // items per wave in the reduction: one per l
 //       Independent waves (blockIdx.y) take the independent jobs.
 //   The last level leaves  F_0 = sum a,  F_1 .. F_L  (v of level 2 .. L + 1) per set; the powers of two that
 //   belong to them (32 lb, 32^2 lb, ..) are applied in the host fold, where a doubling costs well under 1 us.
+//   Levels run on the device until at most four items per set are left; the host fold does that last level itself.
 __global__ void __launch_bounds__(64, 2) msm_bucket_wave_kernel(const u32x4* buckets, u32 nbuckets, u32 lb, u32 log_lb,
                                                                 u32 n1, u32 finalize, u32x4* out_a, u32x4* out_w) {
   const u32 set = blockIdx.x / n1, w = blockIdx.x % n1;
