@@ -646,6 +646,10 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   // small sets (an 8-way shard with 2^15 buckets: 1.00 ms with 2, 1.05 ms with 1; profiles/r02_msm_lb.txt).
   u32 lb_auto = 2;
   while (lb_auto < 64 && (total_buckets / lb_auto) > ((size_t)ctx->num_cus * 4 * 64)) lb_auto *= 2;
+  // ... and mid-size sets (2^13 .. 2^15 buckets) take up to 8 so that level 1 leaves at most 128 items per set: ONE
+  // follow-up launch (128 -> 4, the host does the rest) instead of two; a launch is a ~100 us chain whatever its size
+  // (profiles/r03_small_msm.txt: batch of four at 2^16 points, 1.35 -> 1.29 ms)
+  while (lb_auto < 8 && g.nbuckets / lb_auto > 128 * GROUP && g.nbuckets / 8 <= 128 * GROUP) lb_auto *= 2;
   const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : lb_auto, g.nbuckets);
   u32 log_lb = 0;
   while ((1u << log_lb) < LB) ++log_lb;
