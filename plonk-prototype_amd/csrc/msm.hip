@@ -1223,6 +1223,7 @@ extern "C" int pm_g1_to_affine(const uint64_t xyz[18], uint64_t xy[12], int* is_
 // come back as (0, 0)): what a prover round's batch of commitments needs -- a host inversion is ~50 us.
 extern "C" int pm_g1_to_affine_batch(const uint64_t* xyz, size_t k, uint64_t* xy, int* is_identity) {
   if ((!xyz || !xy) && k) return PM_ERR_BAD_ARG;
+  if (k == 0) return PM_OK;   // (memset / memcpy on a null pointer are undefined even for zero bytes)
   const host::Field<6>& F = host::FP();
   std::vector<HFp> Z(k), pre(k);
   HFp acc = host::one(F);
