@@ -706,6 +706,31 @@ def main():
                 "verifier_identity_holds": bool(pa.prover.check_identity(m_proof, gn, 0))}
             m_wit.free()
             m_key.free()
+            # small circuits: latency of one proof (a chain of four batched MSM calls of ~0.5 ms each, not a throughput
+            # number); 2^12 is the domain of BASELINE configs[0], the reference's own CPU-runnable circuit
+            small = {}
+            for sk_ in (12, 16):
+                if sk_ >= gk:
+                    continue
+                sn_ = 1 << sk_
+                c_s, w_s, p_s = pa.synthetic.chain_circuit(sn_, 5)
+                ck_s = pa.CommitKey(pts[:sn_], ctx, precompute=True)
+                key_s = pa.preprocess(c_s, ctx, ck_s)
+                dw_s = pa.DeviceVector.from_host(ctx, w_s.reshape(-1, 4))
+                pub_s = pa.prover.sparse_public_inputs(p_s)
+                pr_s = pa.prove(key_s, ck_s, dw_s, pub_s)
+                pz_s = pa.field.fr_from_limbs(oracle.fr_poly_evaluate(oracle.fr_ntt(p_s, sk_, INVERSE, cores),
+                                                                      pa.field.fr_to_limbs(pr_s.challenges["z"])))
+                assert pa.prover.check_identity(pr_s, sn_, pz_s), "small proof fails the verifier identity"
+                ts_ = []
+                for _ in range(15):
+                    t0 = time.perf_counter()
+                    pa.prove(key_s, ck_s, dw_s, pub_s)
+                    ts_.append(time.perf_counter() - t0)
+                small[f"2^{sk_}"] = round(float(np.median(ts_)) * 1e3, 3)
+                dw_s.free()
+                key_s.free()
+            prover["latency_ms_by_gates"] = dict(small, note="median of 15 proofs each; 2^12 = the domain of BASELINE configs[0]")
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # the same rounds on the host cores: the C restatement composed by oracle/cpu_prover.py, on a
             # bounded sample (a 2^16-gate circuit), outputs compared with a GPU proof of that circuit
