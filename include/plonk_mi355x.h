@@ -142,7 +142,9 @@ int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t l
 
 /* ---- KZG commit: G1 MSM ---------------------------------------------------------------- */
 
-/* Upload n affine bases (CommitKey::powers_of_g) once; they stay resident in HBM. */
+/* Upload n affine bases (CommitKey::powers_of_g) once; they stay resident in HBM.  A pm_bases is read-only after
+ * pm_g1_bases_precompute and may be used by every context on its device at the same time (several proofs in flight over one
+ * SRS); free it once, after the last call that uses it has returned. */
 int pm_g1_bases_upload(pm_ctx* ctx, const uint64_t* xy, size_t n, pm_bases** out);
 /* Optional, for a long-lived SRS: build the table of window multiples 2^(c w) * bases[i] in HBM
  * ((ceil(256/c) - 1) x 96 n extra bytes; about 8 MSMs of time, once).  Every later MSM on these
