@@ -118,3 +118,42 @@ def test_one_context_per_thread_proves_the_same_bytes(ctx, oracle):
     _run_threads([worker(i) for i in range(len(cases))])
     for i in range(len(cases)):
         assert got[i] == [want[i]] * 5, i
+
+
+def test_contexts_share_one_resident_srs(ctx, oracle):
+    """include/plonk_mi355x.h: a pm_bases is read-only after precompute and may be used by every context of its device at the
+    same time.  Four contexts, one window table: commitments and proofs equal the lone context's."""
+    import plonk_prototype_amd as pa
+    n = 1024
+    srs = oracle.g1_bases_arith(ints_to_limbs([0x51], 4)[0], ints_to_limbs([0x9E3779B9], 4)[0], n, 4)
+    ck0 = pa.CommitKey(srs, ctx, precompute=True)
+    circuit, wit, pi = pa.synthetic.mixed_circuit(n, 8)
+    want_proof = pa.prover.prove(pa.prover.preprocess(circuit, ctx, ck0), ck0, wit, pi).to_bytes()
+    polys = [oracle.fr_sample(60 + i, n) for i in range(4)]
+    want_commit = [ck0.commit(p) for p in polys]
+    results = [None] * 4
+
+    def worker(i):
+        def run():
+            c = pa.Context(0)
+            view = object.__new__(pa.host.Bases)          # the same pm_bases handle, driven through THIS thread's context
+            view.ctx, view.n, view._h = c, ck0._bases.n, ck0._bases._h
+            try:
+                ck = pa.CommitKey.__new__(pa.CommitKey)
+                ck.ctx, ck._bases = c, view
+                pk = pa.prover.preprocess(circuit, c, ck)
+                out = []
+                for _ in range(6):
+                    out.append((pa.prover.prove(pk, ck, wit, pi).to_bytes(), [ck.commit(p) for p in polys]))
+                results[i] = out
+                pk.free()
+            finally:
+                view._h = None                            # not this view's to free
+                c.close()
+        return run
+
+    _run_threads([worker(i) for i in range(4)])
+    for i in range(4):
+        for proof, commits in results[i]:
+            assert proof == want_proof, i
+            assert all(np.array_equal(a, b) for a, b in zip(commits, want_commit)), i
