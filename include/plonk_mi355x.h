@@ -396,7 +396,8 @@ void pm_keccak_f1600(uint8_t state[200]);
 int pm_ntt_plan(uint32_t log_n, uint32_t radix_log2[4], uint32_t* n_passes);
 /* Override tunables: "msm_window_bits", "msm_chunk", "msm_lb", "msm_max_pairs", "msm_pipeline" (1 = a batched MSM as
  * pipelined pieces on two streams; off: it measured slower), "ntt_tile_log", "ntt_radix", "ntt_max_radix", "ntt_xcd",
- * "ntt_direct_tw", "ntt_pipeline" (0 = no copy / compute overlap in pm_fr_ntt_batch).  PM_ERR_BAD_ARG if unknown. */
+ * "ntt_direct_tw", "ntt_pipeline" (0 = no copy / compute overlap in pm_fr_ntt_batch), "poly_lookback" (prefix product in one
+ * pass: 0 never, 1 while all tiles are resident -- the default --, 2 always).  PM_ERR_BAD_ARG if unknown. */
 int pm_set_option(pm_ctx* ctx, const char* key, long value);
 /* Opt-in per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline
  * leg).  pm_profile_read writes lines "<kernel> <launches> <total_ms>\n" into buf. */

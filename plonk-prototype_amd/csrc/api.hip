@@ -270,6 +270,11 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_msm_pipeline = value != 0;
     return PM_OK;
   }
+  if (!strcmp(key, "poly_lookback")) {
+    if (value < 0 || value > 2) return set_err(ctx, PM_ERR_BAD_ARG, "poly_lookback must be 0 (off), 1 (auto) or 2 (always)");
+    ctx->opt_poly_lookback = value;
+    return PM_OK;
+  }
   if (!strcmp(key, "ntt_xcd")) {
     ctx->opt_ntt_xcd = value != 0;
     return PM_OK;

@@ -101,6 +101,7 @@ struct pm_ctx {
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_max_pairs = 0;    // 0 = 2^31 - 1; a batched MSM with more (digit, point) pairs runs in halves
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
+  long opt_poly_lookback = 1;    // prefix product in one pass (decoupled look-back) instead of totals / scan / replay
   long opt_msm_pipeline = 0;     // 1: a batched MSM runs as up to four pieces on two streams (measured: loses, see msm.hip)
   int num_cus = 256;
 };

@@ -287,6 +287,131 @@ __global__ void __launch_bounds__(256) pp_base_kernel(u32x4* v, u32 m) {
   }
 }
 
+// ---- prefix product in ONE pass (r03): decoupled look-back.  One read and one write of the vector instead of two reads
+// and a write plus the launches of the inner levels.  Tiles of SC_TILE elements are handed out by an
+// atomic ticket (a workgroup only ever waits for tiles whose workgroups have started, so they are resident and finish);
+// a tile publishes the product of its elements (status 1) as soon as it has it, then wave 0 walks back over its
+// predecessors' published values, 64 tiles per round, multiplying aggregates until it meets a tile whose INCLUSIVE
+// product is out (status 2), publishes its own inclusive product and replays its elements from the carry.
+// Published values travel through agent-scope atomic stores / loads (the XCDs' L2s are not coherent with each other):
+// value words first, s_waitcnt vmcnt(0), then the status word -- no cache write-back (a fence per tile costs as much as
+// the tile).  Layout of the control block: [ticket | pad to 64 B | status u32 x tiles | 48 B x tiles aggregates |
+// 48 B x tiles inclusive products]; zeroed before every call.
+PM_DEV void pp_publish(u32* slot, const Fr& v) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, v.l[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PM_DEV Fr pp_fetch(const u32* slot) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+__global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_t n, u32x4* out, u32* ctl, u32 tiles) {
+  extern __shared__ u32x4 sc_lds[];
+  __shared__ u32 sh[4 * 9 + 9];
+  __shared__ u32 s_tile;
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  u32* status = ctl + 16;
+  u32* agg = status + ((tiles + 15u) & ~15u);
+  u32* incl = agg + 12 * (size_t)tiles;
+  if (t == 0) s_tile = atomicAdd(ctl, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  if (tile >= tiles) return;
+  const size_t tile0 = (size_t)tile * SC_TILE;
+  u32 w[SC_K][8];
+  tile_load(in, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
+  const size_t lo = tile0 + (size_t)t * SC_K;
+  const Fr one = fe_one<FrP>();
+  // 1 the thread's product, then the inclusive scan over the workgroup's threads (as pp_base_kernel)
+  Fr a[SC_K];
+  Fr tot = one;
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    a[k] = lo + k < n ? abi_to_dev(fe_unpack<FrP>(w[k])) : one;
+    tot = k == 0 ? a[0] : fe_mul<FrP>(tot, a[k]);
+  }
+  Fr inc = tot;
+  for (int d = 1; d < 64; d <<= 1) {
+    const Fr o = fr_shfl_up(inc, d);
+    if (lane >= (u32)d) inc = fe_mul<FrP>(inc, o);
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = inc.l[i];
+  }
+  Fr excl = fr_shfl_up(inc, 1);          // product of the earlier threads of this wave
+  if (lane == 0) excl = one;
+  __syncthreads();
+  Fr tile_total = one;
+#pragma unroll
+  for (u32 wv = 0; wv < 4; ++wv) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = sh[wv * 9 + i];
+    if (wv < wave) excl = fe_mul<FrP>(excl, o);
+    tile_total = wv == 0 ? o : fe_mul<FrP>(tile_total, o);
+  }
+  // 2 publish, look back (wave 0), publish the inclusive product
+  if (wave == 0) {
+    Fr carry = one;
+    if (tile > 0) {
+      if (lane == 0) {
+        pp_publish(agg + 12 * (size_t)tile, tile_total);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(status + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // every lane multiplies what it fetches into its OWN running product (one product per round); the product over
+      // the lanes is taken once, after the last round (the tiles in flight are all in the same phase, so the walk goes
+      // back over most of them: ~16 rounds with 1024 resident tiles)
+      Fr mine = one;
+      for (u32 back = 1;; back += 64) {
+        const bool valid = tile >= back + lane;       // predecessor tile - back - lane exists
+        const u32 pred = valid ? tile - back - lane : 0u;
+        u32 st = valid ? 0u : 2u;                     // beyond tile 0: "inclusive product = one"
+        while (valid && st == 0u) {
+          st = __hip_atomic_load(status + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (st == 0u) __builtin_amdgcn_s_sleep(2);
+        }
+        const u64 done = __ballot(st == 2u);          // lanes that hold an inclusive product (or lie beyond the start)
+        const u32 first = (u32)__ffsll((long long)done) - 1u;   // 64 -> none (ffs of 0 is 0: wraps to ~0)
+        if (valid && (done == 0 || lane <= first))
+          mine = fe_mul<FrP>(mine, pp_fetch((st == 2u ? incl : agg) + 12 * (size_t)pred));
+        if (done != 0) break;
+      }
+      // product over the lanes (order is irrelevant in a commutative group)
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        Fr o;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o.l[i] = __shfl_xor(mine.l[i], d);
+        mine = fe_mul<FrP>(mine, o);
+      }
+      carry = mine;
+    }
+    if (lane == 0) {
+      pp_publish(incl + 12 * (size_t)tile, fe_mul<FrP>(carry, tile_total));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sh[36 + i] = carry.l[i];
+    }
+  }
+  __syncthreads();
+  // 3 replay from the carry: out_k = (everything before element k), ABI form
+  Fr run;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) run.l[i] = sh[36 + i];
+  run = fe_mul<FrP>(fe_mul<FrP>(run, excl), fe_pow2<FrP, 256>());   // device form -> ABI form; ABI x device stays ABI
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    fe_canon_pack<FrP>(w[k], run);
+    run = fe_mul<FrP>(run, a[k]);
+  }
+  tile_store(out, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
+}
+
 // ---- Ruffini.  Level 0 reads the coefficients top down: d_k = c_{n-1-k}, k < m = n - 1, and writes
 // out[m-1-k] = y_k; inner levels hold ABI-form 48-byte entries (lazily reduced) and are scanned in place.
 // y = d + z y: ABI + device x ABI stays ABI form, value < 3 r, limbs < 2^30.
@@ -685,6 +810,33 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   if (!d_in || !d_out) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  // One pass (pp_lookback_kernel) while every tile is resident at once (four workgroups per CU): 2^16 51.8 -> 31.9 us,
+  // 2^18 71.4 -> 35.6, 2^20 93.5 -> 61.7, 2^21 135 -> 109; with a second generation of tiles the walk back over the
+  // ~1000 tiles in flight (all in the same phase: none has its inclusive product yet) is paid per generation and the
+  // three-stage scan below is as fast (2^22: 195 vs 197 us) or faster (2^24: 708 vs 584 us) -- profiles/r03_poly_rows.txt.
+  // opt_poly_lookback: 0 = never, 1 = by this rule, 2 = whenever there is more than one tile (tests).
+  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 4 * (size_t)ctx->num_cus;
+  if (ctx->opt_poly_lookback && n > (size_t)SC_TILE && n <= lookback_max) {
+    // ticket + status + two 48-byte values per tile, zeroed per call
+    const u32 tiles = (u32)((n + SC_TILE - 1) / SC_TILE);
+    const size_t ctl_bytes = 64 + (size_t)((tiles + 15u) & ~15u) * 4 + 2 * (size_t)tiles * 48;
+    OrderScope order_scope(ctx, ctx->ord_poly, st);
+    int rc = order_scope.rc;
+    if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, ctl_bytes);
+    if (rc) return rc;
+    const size_t lds = (size_t)SC_LDS_SLOTS * 16;
+    const void* fn = (const void*)pp_lookback_kernel;
+    if (!ctx->big_lds_set[fn]) {
+      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ctx->big_lds_set[fn] = true;
+    }
+    ProfScope prof(ctx, st, "fr_prefix_product");
+    PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, 64 + (size_t)((tiles + 15u) & ~15u) * 4, st));
+    hipLaunchKernelGGL(pp_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_in, n, (u32x4*)d_out,
+                       (u32*)ctx->poly_ws.ptr, tiles);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+  }
   std::vector<size_t> sz;
   sz.push_back(n);
   while (sz.back() > (size_t)SC_BASE) sz.push_back((sz.back() + SC_K - 1) / SC_K);

@@ -78,7 +78,13 @@ def test_prefix_product(ctx, oracle, n):
     a = oracle.fr_sample(21 + n, n)
     if n > 6000:
         a[5000] = 0                                       # everything after a zero factor is zero
-    assert np.array_equal(_poly(ctx, a).prefix_product().to_host(), oracle.fr_prefix_product(a)), n
+    want = oracle.fr_prefix_product(a)
+    try:
+        for mode in (1, 0, 2):                            # the library's choice, the three-stage scan, the one-pass look-back
+            ctx.set_option("poly_lookback", mode)
+            assert np.array_equal(_poly(ctx, a).prefix_product().to_host(), want), (n, mode)
+    finally:
+        ctx.set_option("poly_lookback", 1)
 
 
 def test_errors(ctx, oracle):

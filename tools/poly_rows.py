@@ -10,6 +10,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n = 1 << k
 o = CpuOracle()
 ctx = pa.Context(0)
+if os.environ.get("PM_POLY_LOOKBACK") is not None:            # A/B: 0 = the three-stage scan (totals / scan / replay)
+    ctx.set_option("poly_lookback", int(os.environ["PM_POLY_LOOKBACK"]))
 va = pa.DeviceVector.from_host(ctx, o.fr_sample(11, n))
 vo = pa.DeviceVector(ctx, n)
 pt = o.fr_sample(13, 1)[0]
