@@ -544,6 +544,150 @@ __global__ void __launch_bounds__(256) ruf_base_kernel(u32x4* v, u32 m, const Ru
     y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), a));
   }
 }
+// Ruffini in ONE pass (r03): the same decoupled look-back as pp_lookback_kernel, for y_k = d_k + z y_{k-1}.  A tile's
+// published value is the y at its end computed from a zero start (status 1) or from the true carry (status 2); a value
+// `b` tiles back enters this tile multiplied by (z^SC_TILE)^(b-1), so every lane of the walking wave keeps its own
+// power of z^SC_TILE (one product per round) next to its running sum.  Forms as in the kernels above: values ABI,
+// multipliers device.
+struct RufLook {
+  u32 z[9];        // z
+  u32 zt[9];       // z^SC_TILE
+  u32 zt64[9];     // z^(64 SC_TILE)
+};
+__global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, u32x4* out,
+                                                            u32* ctl, u32 tiles, const RufLook lk) {
+  extern __shared__ u32x4 sc_lds[];
+  __shared__ u32 sh[4 * 9 + 9 + 9];
+  __shared__ u32 s_tile;
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  u32* status = ctl + 16;
+  u32* agg = status + ((tiles + 15u) & ~15u);
+  u32* incl = agg + 12 * (size_t)tiles;
+  if (t == 0) s_tile = atomicAdd(ctl, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  if (tile >= tiles) return;
+  const size_t tile0 = (size_t)tile * SC_TILE;
+  u32 w[SC_K][8];
+  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+  const size_t lo = tile0 + (size_t)t * SC_K;
+  const Fr z = fr_limbs(lk.z), one = fe_one<FrP>(), zero = fe_zero<FrP>();
+  // 1 the thread's chunk from a zero start (a short last chunk is padded at the end with zeros: y -> z y)
+  Fr d[SC_K];
+  Fr y = zero;
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    d[k] = lo + k < m ? fe_unpack<FrP>(w[k]) : zero;
+    y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
+  }
+  // 2 inclusive scan over the threads of the wave: Y_t = y_t + z^SC_K Y_{t-1}; beside it the powers z^(SC_K (lane + 1))
+  Fr zp = z;
+  for (int i = 1; i < SC_K; i <<= 1) zp = fe_mul<FrP>(zp, zp);   // z^SC_K
+  Fr inc = y, pw = zp;
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const Fr o = fr_shfl_up(inc, dd), po = fr_shfl_up(pw, dd);
+    if (lane >= (u32)dd) {
+      inc = fe_reduce_weak<FrP>(fe_add<FrP>(inc, fe_mul<FrP>(o, zp)));
+      pw = fe_mul<FrP>(pw, po);
+    }
+    zp = fe_mul<FrP>(zp, zp);
+  }
+  // zp = z^(SC_K 64): one wave's span; pw = z^(SC_K (lane + 1))
+  if (lane == 63) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = inc.l[i];
+  }
+  Fr carry = fr_shfl_up(inc, 1), mult = fr_shfl_up(pw, 1);   // y before this thread inside the wave; z^(SC_K lane)
+  if (lane == 0) {
+    carry = zero;
+    mult = one;
+  }
+  __syncthreads();
+  // what enters this wave from the earlier waves of the tile (zero start), and the tile's total; the thread's
+  // multiplier for whatever enters the TILE: z^(SC_K (64 wave + lane))
+  Fr wcar = zero, tile_total = zero;
+#pragma unroll
+  for (u32 wv = 0; wv < 4; ++wv) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.l[i] = sh[wv * 9 + i];
+    if (wv < wave) {
+      wcar = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(wcar, zp), o));
+      mult = fe_mul<FrP>(mult, zp);
+    }
+    tile_total = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(tile_total, zp), o));
+  }
+  if (wave > 0) carry = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(wcar, fr_shfl_up(pw, 1))));
+  // (lane 0 of a later wave: fr_shfl_up leaves its own pw, but its in-wave multiplier is one: fix below)
+  if (wave > 0 && lane == 0) carry = wcar;
+  // 3 publish, look back (wave 0), publish the inclusive value
+  if (wave == 0) {
+    Fr C = zero;
+    if (tile > 0) {
+      if (lane == 0) {
+        pp_publish(agg + 12 * (size_t)tile, tile_total);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(status + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // this lane's power: (z^SC_TILE)^(back - 1 + lane)
+      const Fr zt = fr_limbs(lk.zt), zt64 = fr_limbs(lk.zt64);
+      Fr lp = zt;
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const Fr po = fr_shfl_up(lp, dd);
+        if (lane >= (u32)dd) lp = fe_mul<FrP>(lp, po);
+      }
+      lp = fr_shfl_up(lp, 1);                      // zt^lane
+      if (lane == 0) lp = one;
+      Fr mine = zero;
+      for (u32 back = 1;; back += 64) {
+        const bool valid = tile >= back + lane;
+        const u32 pred = valid ? tile - back - lane : 0u;
+        u32 stt = valid ? 0u : 2u;                  // beyond tile 0: "inclusive value = zero"
+        while (valid && stt == 0u) {
+          stt = __hip_atomic_load(status + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (stt == 0u) __builtin_amdgcn_s_sleep(2);
+        }
+        const u64 done = __ballot(stt == 2u);
+        const u32 first = (u32)__ffsll((long long)done) - 1u;
+        if (valid && (done == 0 || lane <= first))
+          mine = fe_reduce_weak<FrP>(fe_add<FrP>(mine, fe_mul<FrP>(pp_fetch((stt == 2u ? incl : agg) + 12 * (size_t)pred), lp)));
+        if (done != 0) break;
+        lp = fe_mul<FrP>(lp, zt64);
+      }
+#pragma unroll
+      for (int dd = 32; dd > 0; dd >>= 1) {
+        Fr o;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o.l[i] = __shfl_xor(mine.l[i], dd);
+        mine = fe_reduce_weak<FrP>(fe_add<FrP>(mine, o));
+      }
+      C = mine;
+    }
+    if (lane == 0) {
+      const Fr zt = fr_limbs(lk.zt);
+      pp_publish(incl + 12 * (size_t)tile, fe_reduce_weak<FrP>(fe_add<FrP>(tile_total, fe_mul<FrP>(C, zt))));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sh[36 + i] = C.l[i];
+    }
+  }
+  __syncthreads();
+  // 4 replay from y before the thread's chunk = (zero-start carry) + z^(SC_K thread) C
+  Fr C;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C.l[i] = sh[36 + i];
+  y = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(C, mult)));
+#pragma unroll
+  for (int k = 0; k < SC_K; ++k) {
+    if (lo + k < m) {
+      y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
+      fe_canon_pack<FrP>(w[k], y);
+    }
+  }
+  tile_store(out, (long long)(m - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+}
+
 // z == 0: q_{i-1} = c_i
 __global__ void ruffini_shift_kernel(const u32x4* coeffs, u32x4* out, size_t m) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,6 +885,35 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   if (host::is_zero(zz)) {
     hipLaunchKernelGGL(ruffini_shift_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st,
                        (const u32x4*)d_coeffs, (u32x4*)d_out, m);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+  }
+  // one pass (see pm_fr_prefix_product_dev) while the tiles are few: this recurrence costs ~4.5 products per element in one
+  // pass (the powers of z every thread and every look-back lane needs) against 2.2 in three stages -- 2^16 69.7 -> 44.5 us,
+  // 2^18 87.2 -> 48.6, 2^20 112 -> 101, but 2^21 155 -> 191: up to 2.5 tiles per CU (profiles/r03_poly_rows.txt)
+  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 5 * (size_t)ctx->num_cus / 2;
+  if (ctx->opt_poly_lookback && m > (size_t)SC_TILE && m <= lookback_max) {
+    const u32 tiles = (u32)((m + SC_TILE - 1) / SC_TILE);
+    const size_t head = 64 + (size_t)((tiles + 15u) & ~15u) * 4;
+    OrderScope order_scope(ctx, ctx->ord_poly, st);
+    int rc = order_scope.rc;
+    if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, head + 2 * (size_t)tiles * 48);
+    if (rc) return rc;
+    RufLook lk2;
+    const HFr zt = hfr_pow_u64(zz, SC_TILE);
+    to_limbs29(lk2.z, zz);
+    to_limbs29(lk2.zt, zt);
+    to_limbs29(lk2.zt64, hfr_pow_u64(zt, 64));
+    const size_t lds = (size_t)SC_LDS_SLOTS * 16;
+    const void* fn = (const void*)ruf_lookback_kernel;
+    if (!ctx->big_lds_set[fn]) {
+      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ctx->big_lds_set[fn] = true;
+    }
+    ProfScope prof(ctx, st, "fr_poly_ruffini");
+    PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, head, st));
+    hipLaunchKernelGGL(ruf_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (u32x4*)d_out,
+                       (u32*)ctx->poly_ws.ptr, tiles, lk2);
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
   }

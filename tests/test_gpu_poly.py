@@ -40,13 +40,18 @@ def test_evaluate(ctx, oracle, n):
     assert np.array_equal(_poly(ctx, c).evaluate(one), oracle.fr_poly_evaluate(c, one))      # p(1) = sum c_i
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 256, 257, 258, 5000, (1 << 16) + 1, (1 << 20) + 5])
+@pytest.mark.parametrize("n", [1, 2, 3, 256, 257, 258, 2048, 2049, 2050, 4097, 5000, (1 << 16) + 1, (1 << 20) + 5, (1 << 21) + 3])
 def test_ruffini(ctx, oracle, n):
     c = oracle.fr_sample(7 + n, n)
-    for z in (oracle.fr_sample(9, 1)[0], np.zeros(4, np.uint64), oracle.fr_to_mont(ints_to_limbs([1], 4))[0]):
-        q = _poly(ctx, c).ruffini(z).to_host()
-        assert q.shape[0] == n - 1
-        assert np.array_equal(q, oracle.fr_poly_ruffini(c, z)), n
+    try:
+        for mode in (1, 0, 2):                            # the library's choice, the three-stage scan, the one-pass look-back
+            ctx.set_option("poly_lookback", mode)
+            for z in (oracle.fr_sample(9, 1)[0], np.zeros(4, np.uint64), oracle.fr_to_mont(ints_to_limbs([1], 4))[0]):
+                q = _poly(ctx, c).ruffini(z).to_host()
+                assert q.shape[0] == n - 1
+                assert np.array_equal(q, oracle.fr_poly_ruffini(c, z)), (n, mode)
+    finally:
+        ctx.set_option("poly_lookback", 1)
     if n > 1:   # q(X) (X - z) + c(z) == c(X) at a random point (the defining identity)
         z = oracle.fr_sample(9, 1)[0]
         q = _poly(ctx, c).ruffini(z)
@@ -73,7 +78,7 @@ def test_batch_inverse(ctx, oracle, n):
     assert np.array_equal(prod[nz], np.broadcast_to(one, (int(nz.sum()), 4))) and not prod[~nz].any()
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 5000, 1 << 16, (1 << 20) + 3, (1 << 21) + (1 << 19)])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 4096, 4097, 5000, 1 << 16, (1 << 20) + 3, (1 << 21) + (1 << 19)])
 def test_prefix_product(ctx, oracle, n):
     a = oracle.fr_sample(21 + n, n)
     if n > 6000:
