@@ -534,6 +534,15 @@ def main():
             sec = timed(fn)
             poly[name] = {"us": round(sec * 1e6, 1), "GB/s": round(nbytes / sec / 1e9, 1),
                           "hbm_frac": round(nbytes / sec / HBM_PEAK, 4)}
+        # the two scans at the prover's own size (2^20: the one-pass look-back applies there, the 2^22 rows above use the
+        # three-stage scan)
+        qn = 1 << 20
+        at20 = {}
+        for name, fn in (("poly_ruffini", lambda: lib.pm_fr_poly_ruffini_dev(h, va._p, qn, pp, vo._p, None)),
+                         ("prefix_product", lambda: lib.pm_fr_prefix_product_dev(h, va._p, qn, vo._p, None))):
+            sec = timed(fn)
+            at20[name] = {"us": round(sec * 1e6, 1), "hbm_frac": round(64 * qn / sec / HBM_PEAK, 4)}
+        poly["at_2^20"] = at20
         for v in (va, vb, vo):
             v.free()
 
