@@ -293,28 +293,38 @@ __global__ void __launch_bounds__(256) pp_base_kernel(u32x4* v, u32 m) {
 // a tile publishes the product of its elements (status 1) as soon as it has it, then wave 0 walks back over its
 // predecessors' published values, 64 tiles per round, multiplying aggregates until it meets a tile whose INCLUSIVE
 // product is out (status 2), publishes its own inclusive product and replays its elements from the carry.
-// Published values travel through agent-scope atomic stores / loads (the XCDs' L2s are not coherent with each other):
-// value words first, s_waitcnt vmcnt(0), then the status word -- no cache write-back (a fence per tile costs as much as
-// the tile).  Layout of the control block: [ticket | pad to 64 B | status u32 x tiles | 48 B x tiles aggregates |
-// 48 B x tiles inclusive products]; zeroed before every call.
-PM_DEV void pp_publish(u32* slot, const Fr& v) {
+// Published values travel through agent-scope atomic stores / loads (the XCDs' L2s are not coherent with each other)
+// and carry their own validity (pp_publish / pp_fetch below) -- no status word, no cache write-back (a fence per tile
+// costs as much as the tile).  Layout of the control block: [ticket | pad to 64 B | 48 B x tiles records]; zeroed
+// before every call.
+// A tile's record: nine words, each a 29-bit limb with a 2-bit tag above it (1: the zero-start value, 2: the inclusive
+// value; the record is overwritten once, 1 -> 2).  Every word is written and read atomically and validates itself: a
+// reader takes the record when all nine tags agree, whichever of the two values that is, and reads again otherwise --
+// one round trip per look-back round, no status word, no ordering between the stores.
+PM_DEV void pp_publish(u32* slot, const Fr& v, u32 tag) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, v.l[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, v.l[i] | (tag << 30), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-PM_DEV Fr pp_fetch(const u32* slot) {
-  Fr r;
+PM_DEV u32 pp_fetch(const u32* slot, Fr& v) {   // -> the tag, 0 = not there yet (or caught between the two values)
+  u32 w[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r.l[i] = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return r;
+  for (int i = 0; i < 9; ++i) w[i] = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32 lo = w[0] >> 30, hi = lo;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    lo = lo < (w[i] >> 30) ? lo : (w[i] >> 30);
+    hi = hi > (w[i] >> 30) ? hi : (w[i] >> 30);
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v.l[i] = w[i] & 0x3fffffffu;
+  return lo == hi ? lo : 0u;
 }
 __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_t n, u32x4* out, u32* ctl, u32 tiles) {
   extern __shared__ u32x4 sc_lds[];
   __shared__ u32 sh[4 * 9 + 9];
   __shared__ u32 s_tile;
   const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  u32* status = ctl + 16;
-  u32* agg = status + ((tiles + 15u) & ~15u);
-  u32* incl = agg + 12 * (size_t)tiles;
+  u32* rec = ctl + 16;                    // 12 words per tile
   if (t == 0) s_tile = atomicAdd(ctl, 1u);
   __syncthreads();
   const u32 tile = s_tile;
@@ -357,11 +367,7 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
   if (wave == 0) {
     Fr carry = one;
     if (tile > 0) {
-      if (lane == 0) {
-        pp_publish(agg + 12 * (size_t)tile, tile_total);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(status + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (lane == 0) pp_publish(rec + 12 * (size_t)tile, tile_total, 1u);
       // every lane multiplies what it fetches into its OWN running product (one product per round); the product over
       // the lanes is taken once, after the last round (the tiles in flight are all in the same phase, so the walk goes
       // back over most of them: ~16 rounds with 1024 resident tiles)
@@ -370,14 +376,14 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
         const bool valid = tile >= back + lane;       // predecessor tile - back - lane exists
         const u32 pred = valid ? tile - back - lane : 0u;
         u32 st = valid ? 0u : 2u;                     // beyond tile 0: "inclusive product = one"
+        Fr got = one;
         while (valid && st == 0u) {
-          st = __hip_atomic_load(status + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (st == 0u) __builtin_amdgcn_s_sleep(2);
+          st = pp_fetch(rec + 12 * (size_t)pred, got);
+          if (st == 0u) __builtin_amdgcn_s_sleep(1);
         }
         const u64 done = __ballot(st == 2u);          // lanes that hold an inclusive product (or lie beyond the start)
-        const u32 first = (u32)__ffsll((long long)done) - 1u;   // 64 -> none (ffs of 0 is 0: wraps to ~0)
-        if (valid && (done == 0 || lane <= first))
-          mine = fe_mul<FrP>(mine, pp_fetch((st == 2u ? incl : agg) + 12 * (size_t)pred));
+        const u32 first = (u32)__ffsll((long long)done) - 1u;   // (ffs of 0 is 0: wraps to ~0 = none)
+        if (valid && (done == 0 || lane <= first)) mine = fe_mul<FrP>(mine, got);
         if (done != 0) break;
       }
       // product over the lanes (order is irrelevant in a commutative group)
@@ -391,9 +397,7 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
       carry = mine;
     }
     if (lane == 0) {
-      pp_publish(incl + 12 * (size_t)tile, fe_mul<FrP>(carry, tile_total));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pp_publish(rec + 12 * (size_t)tile, fe_mul<FrP>(carry, tile_total), 2u);
 #pragma unroll
       for (int i = 0; i < 9; ++i) sh[36 + i] = carry.l[i];
     }
@@ -560,9 +564,7 @@ __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, 
   __shared__ u32 sh[4 * 9 + 9 + 9];
   __shared__ u32 s_tile;
   const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  u32* status = ctl + 16;
-  u32* agg = status + ((tiles + 15u) & ~15u);
-  u32* incl = agg + 12 * (size_t)tiles;
+  u32* rec = ctl + 16;                    // 12 words per tile
   if (t == 0) s_tile = atomicAdd(ctl, 1u);
   __syncthreads();
   const u32 tile = s_tile;
@@ -624,11 +626,7 @@ __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, 
   if (wave == 0) {
     Fr C = zero;
     if (tile > 0) {
-      if (lane == 0) {
-        pp_publish(agg + 12 * (size_t)tile, tile_total);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(status + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (lane == 0) pp_publish(rec + 12 * (size_t)tile, tile_total, 1u);
       // this lane's power: (z^SC_TILE)^(back - 1 + lane)
       const Fr zt = fr_limbs(lk.zt), zt64 = fr_limbs(lk.zt64);
       Fr lp = zt;
@@ -643,14 +641,14 @@ __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, 
         const bool valid = tile >= back + lane;
         const u32 pred = valid ? tile - back - lane : 0u;
         u32 stt = valid ? 0u : 2u;                  // beyond tile 0: "inclusive value = zero"
+        Fr got = zero;
         while (valid && stt == 0u) {
-          stt = __hip_atomic_load(status + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (stt == 0u) __builtin_amdgcn_s_sleep(2);
+          stt = pp_fetch(rec + 12 * (size_t)pred, got);
+          if (stt == 0u) __builtin_amdgcn_s_sleep(1);
         }
         const u64 done = __ballot(stt == 2u);
         const u32 first = (u32)__ffsll((long long)done) - 1u;
-        if (valid && (done == 0 || lane <= first))
-          mine = fe_reduce_weak<FrP>(fe_add<FrP>(mine, fe_mul<FrP>(pp_fetch((stt == 2u ? incl : agg) + 12 * (size_t)pred), lp)));
+        if (valid && (done == 0 || lane <= first)) mine = fe_reduce_weak<FrP>(fe_add<FrP>(mine, fe_mul<FrP>(got, lp)));
         if (done != 0) break;
         lp = fe_mul<FrP>(lp, zt64);
       }
@@ -665,9 +663,7 @@ __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, 
     }
     if (lane == 0) {
       const Fr zt = fr_limbs(lk.zt);
-      pp_publish(incl + 12 * (size_t)tile, fe_reduce_weak<FrP>(fe_add<FrP>(tile_total, fe_mul<FrP>(C, zt))));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(status + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pp_publish(rec + 12 * (size_t)tile, fe_reduce_weak<FrP>(fe_add<FrP>(tile_total, fe_mul<FrP>(C, zt))), 2u);
 #pragma unroll
       for (int i = 0; i < 9; ++i) sh[36 + i] = C.l[i];
     }
@@ -894,10 +890,10 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 5 * (size_t)ctx->num_cus / 2;
   if (ctx->opt_poly_lookback && m > (size_t)SC_TILE && m <= lookback_max) {
     const u32 tiles = (u32)((m + SC_TILE - 1) / SC_TILE);
-    const size_t head = 64 + (size_t)((tiles + 15u) & ~15u) * 4;
+    const size_t head = 64 + (size_t)tiles * 48;
     OrderScope order_scope(ctx, ctx->ord_poly, st);
     int rc = order_scope.rc;
-    if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, head + 2 * (size_t)tiles * 48);
+    if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, head);
     if (rc) return rc;
     RufLook lk2;
     const HFr zt = hfr_pow_u64(zz, SC_TILE);
@@ -992,7 +988,7 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   if (ctx->opt_poly_lookback && n > (size_t)SC_TILE && n <= lookback_max) {
     // ticket + status + two 48-byte values per tile, zeroed per call
     const u32 tiles = (u32)((n + SC_TILE - 1) / SC_TILE);
-    const size_t ctl_bytes = 64 + (size_t)((tiles + 15u) & ~15u) * 4 + 2 * (size_t)tiles * 48;
+    const size_t ctl_bytes = 64 + (size_t)tiles * 48;
     OrderScope order_scope(ctx, ctx->ord_poly, st);
     int rc = order_scope.rc;
     if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, ctl_bytes);
@@ -1004,7 +1000,7 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
       ctx->big_lds_set[fn] = true;
     }
     ProfScope prof(ctx, st, "fr_prefix_product");
-    PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, 64 + (size_t)((tiles + 15u) & ~15u) * 4, st));
+    PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, ctl_bytes, st));
     hipLaunchKernelGGL(pp_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_in, n, (u32x4*)d_out,
                        (u32*)ctx->poly_ws.ptr, tiles);
     PM_HIP(ctx, hipGetLastError());
