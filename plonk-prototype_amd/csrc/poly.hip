@@ -297,21 +297,31 @@ __global__ void __launch_bounds__(256) pp_base_kernel(u32x4* v, u32 m) {
 // and carry their own validity (pp_publish / pp_fetch below) -- no status word, no cache write-back (a fence per tile
 // costs as much as the tile).  Layout of the control block: [ticket | pad to 64 B | 48 B x tiles records]; zeroed
 // before every call.
-// A tile's record: nine words, each a 29-bit limb with a 2-bit tag above it (1: the zero-start value, 2: the inclusive
+// A tile's record: ten words (five 64-bit stores / loads), each a 29-bit limb (the tenth: zero) with a 2-bit tag above it (1: the zero-start value, 2: the inclusive
 // value; the record is overwritten once, 1 -> 2).  Every word is written and read atomically and validates itself: a
-// reader takes the record when all nine tags agree, whichever of the two values that is, and reads again otherwise --
+// reader takes the record when all ten tags agree, whichever of the two values that is, and reads again otherwise --
 // one round trip per look-back round, no status word, no ordering between the stores.
-PM_DEV void pp_publish(u32* slot, const Fr& v, u32 tag) {
+PM_DEV void pp_publish(u32* slot, const Fr& v, u32 tag) {   // five 64-bit stores: two tagged words each
+  unsigned long long* s64 = reinterpret_cast<unsigned long long*>(slot);
+  const u32 tg = tag << 30;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, v.l[i] | (tag << 30), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < 5; ++i) {
+    const u32 lo = v.l[2 * i] | tg, hi = (2 * i + 1 < 9 ? v.l[2 * i + 1] : 0u) | tg;
+    __hip_atomic_store(s64 + i, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 PM_DEV u32 pp_fetch(const u32* slot, Fr& v) {   // -> the tag, 0 = not there yet (or caught between the two values)
-  u32 w[9];
+  const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(slot);
+  u32 w[10];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < 5; ++i) {
+    const unsigned long long x = __hip_atomic_load(s64 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w[2 * i] = (u32)x;
+    w[2 * i + 1] = (u32)(x >> 32);
+  }
   u32 lo = w[0] >> 30, hi = lo;
 #pragma unroll
-  for (int i = 1; i < 9; ++i) {
+  for (int i = 1; i < 10; ++i) {
     lo = lo < (w[i] >> 30) ? lo : (w[i] >> 30);
     hi = hi > (w[i] >> 30) ? hi : (w[i] >> 30);
   }
@@ -319,6 +329,7 @@ PM_DEV u32 pp_fetch(const u32* slot, Fr& v) {   // -> the tag, 0 = not there yet
   for (int i = 0; i < 9; ++i) v.l[i] = w[i] & 0x3fffffffu;
   return lo == hi ? lo : 0u;
 }
+constexpr u32 PP_AHEAD = 4;   // look-back rounds whose records are requested together
 __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_t n, u32x4* out, u32* ctl, u32 tiles) {
   extern __shared__ u32x4 sc_lds[];
   __shared__ u32 sh[4 * 9 + 9];
@@ -372,19 +383,30 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
       // the lanes is taken once, after the last round (the tiles in flight are all in the same phase, so the walk goes
       // back over most of them: ~16 rounds with 1024 resident tiles)
       Fr mine = one;
-      for (u32 back = 1;; back += 64) {
-        const bool valid = tile >= back + lane;       // predecessor tile - back - lane exists
-        const u32 pred = valid ? tile - back - lane : 0u;
-        u32 st = valid ? 0u : 2u;                     // beyond tile 0: "inclusive product = one"
-        Fr got = one;
-        while (valid && st == 0u) {
-          st = pp_fetch(rec + 12 * (size_t)pred, got);
-          if (st == 0u) __builtin_amdgcn_s_sleep(1);
+      bool finished = false;
+      for (u32 back = 1; !finished; back += 64 * PP_AHEAD) {
+        // the records of PP_AHEAD rounds are requested together (one round trip instead of PP_AHEAD), then taken in order
+        bool valid[PP_AHEAD];
+        u32 st[PP_AHEAD];
+        Fr got[PP_AHEAD];
+#pragma unroll
+        for (u32 u = 0; u < PP_AHEAD; ++u) {
+          valid[u] = tile >= back + 64 * u + lane;    // predecessor tile - back - 64 u - lane exists
+          st[u] = valid[u] ? pp_fetch(rec + 12 * (size_t)(tile - back - 64 * u - lane), got[u]) : 2u;   // beyond tile 0: "inclusive product = one"
+          if (!valid[u]) got[u] = one;
         }
-        const u64 done = __ballot(st == 2u);          // lanes that hold an inclusive product (or lie beyond the start)
-        const u32 first = (u32)__ffsll((long long)done) - 1u;   // (ffs of 0 is 0: wraps to ~0 = none)
-        if (valid && (done == 0 || lane <= first)) mine = fe_mul<FrP>(mine, got);
-        if (done != 0) break;
+#pragma unroll
+        for (u32 u = 0; u < PP_AHEAD; ++u) {
+          if (finished) break;
+          while (valid[u] && st[u] == 0u) {
+            __builtin_amdgcn_s_sleep(1);
+            st[u] = pp_fetch(rec + 12 * (size_t)(tile - back - 64 * u - lane), got[u]);
+          }
+          const u64 done = __ballot(st[u] == 2u);     // lanes that hold an inclusive product (or lie beyond the start)
+          const u32 first = (u32)__ffsll((long long)done) - 1u;   // (ffs of 0 is 0: wraps to ~0 = none)
+          if (valid[u] && (done == 0 || lane <= first)) mine = fe_mul<FrP>(mine, got[u]);
+          finished = done != 0;
+        }
       }
       // product over the lanes (order is irrelevant in a commutative group)
 #pragma unroll
