@@ -49,6 +49,11 @@ class stdout_to_stderr:
 
 
 def main():
+    # stdout carries exactly ONE line, the result: file descriptor 1 points at stderr for the whole run (RCCL, gloo and the
+    # HIP runtime print banners on stdout from native code, on every rank), and the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -832,7 +837,8 @@ def main():
                             if native_comm else f"torch.distributed ({backend})"),
                "roofline": roofline, "cpu_baseline": cpu, "ntt_extra": ntt_extra, "ntt_fourstep": fourstep, "msm": msm, "msm_large": msm_large, "next_rows": poly,
                "prover": prover}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
