@@ -90,7 +90,9 @@ int pm_sync(pm_ctx* ctx);
 /* Give back what the context caches between calls -- pass buffers, MSM / polynomial workspaces, staging, twiddle tables --
  * after waiting for the device; everything is rebuilt or regrown on demand (a workspace only ever grows otherwise: after
  * one 2^30-point transform a context holds 77 GB of pass buffers).  pm_bases and pm_prover_key objects are untouched.
- * freed_bytes (may be NULL): device memory returned to the driver. */
+ * freed_bytes (may be NULL): device memory returned to the driver.  May be called at any time from any thread; while a
+ * pm_fr_ntt_fourstep_dev call of another thread is between two of its exchange steps on this context (it keeps table
+ * pointers across them) the call changes nothing and returns PM_ERR_BUSY. */
 int pm_trim(pm_ctx* ctx, size_t* freed_bytes);
 
 /* ---- EvaluationDomain ------------------------------------------------------------------ */
@@ -319,7 +321,9 @@ int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_
  * PM_PLONK_UPSTREAM_TRANSCRIPT reproduces the restated upstream message sequence byte for byte and is what a drop-in
  * for dusk's Prover must pass ("Transcript modes").  The two modes agree up to and including the
  * four wire commitments and differ from `beta` on.  PM_PLONK_BIND_PUBLIC_INPUTS (r01/r02 spelling of the default) is
- * accepted and ignored. */
+ * accepted and ignored; both flags together contradict each other: PM_ERR_BAD_ARG.
+ * CHANGE r03: up to r02 flags = 0 meant the upstream sequence and binding was opt-in; a C caller that passed 0 and
+ * needs the r02 bytes must now pass PM_PLONK_UPSTREAM_TRANSCRIPT. */
 #define PM_PLONK_BIND_PUBLIC_INPUTS 1u
 #define PM_PLONK_UPSTREAM_TRANSCRIPT 2u
 typedef struct pm_prover_key pm_prover_key;
@@ -407,15 +411,10 @@ int pm_profile_enable(pm_ctx* ctx, int on);
 int pm_profile_select(pm_ctx* ctx, const char* kernel_name);
 int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap);
 /* Elementwise field kernels used by the parity tests: op 0 = Fr mul, 1 = Fr add, 2 = Fr sub,
- * 3 = Fp mul, 4 = Fp add, 5 = Fp sub, 6 = Fr inverse of a, 7 = Fp inverse of a (b ignored; 0 -> 0).  Host pointers,
+ * 3 = Fp mul, 4 = Fp add, 5 = Fp sub, 6 = Fr inverse of a, 7 = Fp inverse of a (b ignored, may be NULL; 0 -> 0).  Host pointers,
  * n elements. */
 int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                      size_t n);
-/* Pure host, no context: the bucket-fill layout (csrc/msm_sort.hip.h) an MSM of this shape would run with -- out[16] =
- * {window bits, windows, bucket sets, bucket bits, partition bits, local bits, partitions per set, bins, partitions,
- * scalars per scatter tile, tiles, LDS bytes scatter, LDS bytes local sort, finer low partitions, their extra bits, 0} --
- * and, when the three arrays are given (2^bucket-bits / partitions-per-set entries), the partition of every bucket and
- * every partition's first bucket and log2 width.  table_window_bits 0 = bases without a window table. */
 /* Pure host, no device: the library's sizing pass for one MSM piece of this shape -- out[4] = {its return code, device
  * workspace bytes, pinned host bytes, (digit, point) pairs at most}. */
 int pm_test_msm_sizing(size_t n, uint32_t batch, long window_bits, uint32_t table_window_bits, uint32_t num_cus,
@@ -425,6 +424,11 @@ int pm_test_msm_sizing(size_t n, uint32_t batch, long window_bits, uint32_t tabl
  * a kernel, log2 group size of the blocked intermediate layout, 0}. */
 int pm_test_ntt_plan(uint32_t log_n, uint32_t batch, long tile_log, long max_radix, long radix, uint32_t num_cus,
                      uint32_t out[20]);
+/* Pure host, no context: the bucket-fill layout (csrc/msm_sort.hip.h) an MSM of this shape would run with -- out[16] =
+ * {window bits, windows, bucket sets, bucket bits, partition bits, local bits, partitions per set, bins, partitions,
+ * scalars per scatter tile, tiles, LDS bytes scatter, LDS bytes local sort, finer low partitions, their extra bits, 0} --
+ * and, when the three arrays are given (2^bucket-bits / partitions-per-set entries), the partition of every bucket and
+ * every partition's first bucket and log2 width.  table_window_bits 0 = bases without a window table. */
 int pm_test_msm_geometry(size_t n, long window_bits, uint32_t table_window_bits, uint32_t batch, uint32_t out[16],
                          uint32_t* part_of_bucket, uint32_t* first_bucket, uint32_t* width_bits);
 

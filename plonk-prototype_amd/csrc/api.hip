@@ -15,6 +15,17 @@ int set_err(pm_ctx* ctx, int code, const std::string& msg) {
   return code;
 }
 
+int raise_lds_limit(pm_ctx* ctx, const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> limit;   // (device, kernel) -> bytes already granted
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = limit[{ctx->device, fn}];
+  if (bytes <= have) return PM_OK;
+  PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return PM_OK;
+}
+
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   if (b.bytes >= bytes && b.ptr) return PM_OK;
   if (b.ptr) {
@@ -162,6 +173,8 @@ static void release_caches(pm_ctx* ctx, bool all) {
 extern "C" int pm_trim(pm_ctx* ctx, size_t* freed_bytes) {
   if (!ctx) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (ctx->calls_holding_tables > 0)   // a four-step transform of another thread is between two of its exchange steps
+    return set_err(ctx, PM_ERR_BUSY, "pm_trim while a pm_fr_ntt_fourstep_dev call is in flight on this context");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   PM_HIP(ctx, hipDeviceSynchronize());   // the buffers may be in use on any caller stream
   size_t free0 = 0, free1 = 0, total = 0;
@@ -307,9 +320,13 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
 
 extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b,
                                 uint64_t* out, size_t n) {
-  if (!ctx || !a || !b || !out) return PM_ERR_BAD_ARG;
+  if (!ctx || !a || !out) return PM_ERR_BAD_ARG;
+  if (op < 0 || op > 7) return PM_ERR_BAD_ARG;
+  if (!b) {
+    if (op < 6) return PM_ERR_BAD_ARG;
+    b = a;   // the inversions ignore b
+  }
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (op < 0 || op > 7) return set_err(ctx, PM_ERR_BAD_ARG, "op");
   if (n == 0) return PM_OK;
   PM_HIP(ctx, hipSetDevice(ctx->device));
   const size_t esz = (op < 3 || op == 6) ? 32 : 48;

@@ -59,8 +59,7 @@ struct pm_ctx {
   pm::DeviceBuffer ntt_tmp[2];
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
   pm::StreamOrder ord_ntt, ord_msm, ord_poly;           // cross-stream ordering of the shared scratch + tables
-  std::map<const void*, bool> big_lds_set;              // kernels whose dynamic-LDS limit was already raised
-  std::map<const void*, size_t> big_lds;                // ... and the limit set, where it depends on the call
+  int calls_holding_tables = 0;                         // calls that keep table pointers across unlocked sections (four-step NTT): pm_trim refuses
   // MSM workspaces
   pm::DeviceBuffer msm_ws;
   pm::DeviceBuffer msm_ctl;                             // control block of the bucket fill (msm_sort.hip.h): zero when idle
@@ -127,6 +126,10 @@ struct ProfScope {
 };
 int prof_collect(pm_ctx* ctx);
 int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-function attribute of the PROCESS (per device), not of a
+// context: the largest value any context asked for is remembered process-wide and only ever raised (ADVICE r03:
+// with a per-context record, context B could lower what context A had set and A's next launch would fail).
+int raise_lds_limit(pm_ctx* ctx, const void* fn, size_t bytes);
 int comm_alltoall(pm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer, hipStream_t st);   // comm.hip
 struct OrderScope {
   pm_ctx* ctx;

@@ -711,14 +711,8 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
     const size_t lds1 = sort_scatter_lds(g), lds2 = sort_local_lds(g);
     const void* k1 = (const void*)msm_digits_scatter_kernel<SORT_THREADS1>;
     const void* k2 = (const void*)msm_sort_local_kernel;
-    if (ctx->big_lds[k1] < lds1) {
-      PM_HIP(ctx, hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-      ctx->big_lds[k1] = lds1;
-    }
-    if (ctx->big_lds[k2] < lds2) {
-      PM_HIP(ctx, hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      ctx->big_lds[k2] = lds2;
-    }
+    if (int lrc = raise_lds_limit(ctx, k1, lds1)) return lrc;
+    if (int lrc = raise_lds_limit(ctx, k2, lds2)) return lrc;
     {
       ProfScope prof(ctx, st, "msm_digits");
       hipLaunchKernelGGL(msm_digits_hist_kernel<SORT_THREADS0>, dim3(batch * wgs_per_msm), dim3(SORT_THREADS0), (size_t)g.bins * 4, st,

@@ -369,11 +369,8 @@ int ntt_run(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride, void
     a.flags = (i == 0 ? pre : 0u) | post_i | tw_flag | (ctx->opt_ntt_xcd ? PASS_XCD_REMAP : 0u);
     const unsigned threads = r4 ? pass4_threads(S, LT) : std::max(64u, (1u << (S + LT)) / 8);
     const size_t lds = r4 ? pass4_lds(S, LT) : pass_lds_bytes(S, LT);
-    if (lds > 64 * 1024 && !ctx->big_lds_set[(const void*)fn]) {   // once per kernel, not per launch
-      PM_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-      ctx->big_lds_set[(const void*)fn] = true;
-    }
+    if (lds > 64 * 1024)   // once per kernel and process, not per launch
+      if (int lrc = raise_lds_limit(ctx, (const void*)fn, lds)) return lrc;
     const unsigned blocks = (unsigned)(n >> (S + LT));
     {
       static const char* kRoleName[4] = {"ntt_pass_single", "ntt_pass_first", "ntt_pass_middle", "ntt_pass_last"};
@@ -695,6 +692,7 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
       if (!s) return;
       std::lock_guard<std::mutex> lk(ctx->mu);
       delete s;
+      --ctx->calls_holding_tables;
     }
   } held{ctx, nullptr};
   {
@@ -704,6 +702,7 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
     if (world > 1 && !exchange && (!ctx->comm || ctx->comm_world != (int)world || ctx->comm_rank != (int)rank))
       return set_err(ctx, PM_ERR_EXCHANGE, "no exchange callback and no matching communicator (pm_comm_init)");
     held.s = new OrderScope(ctx, ctx->ord_ntt, st);
+    ++ctx->calls_holding_tables;   // dt and the tables behind it stay in use across the unlocked exchange steps: no pm_trim
     int rc = held.s->rc;
     if (!rc) rc = get_domain_tables(ctx, inverse ? 1 : 0, log_n, coset, &dt, st);
     if (rc) return rc;

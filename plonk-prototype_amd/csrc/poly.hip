@@ -924,10 +924,7 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
     to_limbs29(lk2.zt64, hfr_pow_u64(zt, 64));
     const size_t lds = (size_t)SC_LDS_SLOTS * 16;
     const void* fn = (const void*)ruf_lookback_kernel;
-    if (!ctx->big_lds_set[fn]) {
-      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ctx->big_lds_set[fn] = true;
-    }
+    if (int lrc = raise_lds_limit(ctx, fn, lds)) return lrc;
     ProfScope prof(ctx, st, "fr_poly_ruffini");
     PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, head, st));
     hipLaunchKernelGGL(ruf_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (u32x4*)d_out,
@@ -965,10 +962,7 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   }
   const size_t sc_lds_bytes = (size_t)SC_LDS_SLOTS * 16;
   for (const void* fn : {(const void*)ruf_totals0_kernel, (const void*)ruf_replay0_kernel})
-    if (!ctx->big_lds_set[fn]) {
-      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds_bytes));
-      ctx->big_lds_set[fn] = true;
-    }
+    if (int lrc = raise_lds_limit(ctx, fn, sc_lds_bytes)) return lrc;
   ProfScope prof(ctx, st, "fr_poly_ruffini");
   const size_t last = sz.size() - 1;
   for (size_t i = 0; i < last; ++i) {   // totals of level i -> level i + 1
@@ -1017,10 +1011,7 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
     if (rc) return rc;
     const size_t lds = (size_t)SC_LDS_SLOTS * 16;
     const void* fn = (const void*)pp_lookback_kernel;
-    if (!ctx->big_lds_set[fn]) {
-      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      ctx->big_lds_set[fn] = true;
-    }
+    if (int lrc = raise_lds_limit(ctx, fn, lds)) return lrc;
     ProfScope prof(ctx, st, "fr_prefix_product");
     PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, ctl_bytes, st));
     hipLaunchKernelGGL(pp_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_in, n, (u32x4*)d_out,
@@ -1048,10 +1039,7 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   }
   const size_t sc_lds_bytes = (size_t)SC_LDS_SLOTS * 16;
   for (const void* fn : {(const void*)pp_totals0_kernel, (const void*)pp_replay0_kernel})
-    if (!ctx->big_lds_set[fn]) {
-      PM_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds_bytes));
-      ctx->big_lds_set[fn] = true;
-    }
+    if (int lrc = raise_lds_limit(ctx, fn, sc_lds_bytes)) return lrc;
   ProfScope prof(ctx, st, "fr_prefix_product");
   const size_t last = sz.size() - 1;
   for (size_t i = 0; i < last; ++i) {

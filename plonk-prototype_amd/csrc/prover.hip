@@ -405,10 +405,16 @@ struct Shard {
   pm_exchange_fn fn = nullptr; // nullptr with on = true: the context's RCCL communicator (pm_g1_allgather_fold)
   void* user = nullptr;
   mutable bool aborted = false;   // an exchange of this call already carried / returned the abort marker
+  // How many exchanges the call makes on every rank (key commit: slice cover + two batches; proof: four commit batches)
+  // and how many this rank has completed: an error AFTER the last one must not put one more collective on the wire
+  // -- no peer would be waiting for it, and it would pair with the first exchange of the peers' next call.
+  int expect = 0;
+  mutable int done = 0;
 };
 // One exchange of k partial points (k = 0: the abort marker).
 static int shard_exchange(pm_ctx* ctx, const Shard& sh, u64* xyz, uint32_t k) {
   const int rc = sh.fn ? (sh.fn(sh.user, xyz, k) != 0 ? PM_ERR_EXCHANGE : PM_OK) : pm_g1_allgather_fold(ctx, xyz, k);
+  ++sh.done;
   if (k == 0 || rc != PM_OK) sh.aborted = true;
   return k == 0 && rc == PM_OK ? PM_ERR_EXCHANGE : rc;
 }
@@ -416,7 +422,7 @@ static int shard_exchange(pm_ctx* ctx, const Shard& sh, u64* xyz, uint32_t k) {
 // wrong on this rank only -- must still meet its peers in their next collective, or they block in it for ever
 // (ncclAllGather has no timeout): one abort marker, after which every rank returns an error.
 static int shard_leave(pm_ctx* ctx, const Shard& sh, int rc) {
-  if (rc != PM_OK && sh.on && ctx && !sh.aborted) {
+  if (rc != PM_OK && sh.on && ctx && !sh.aborted && sh.done < sh.expect) {
     u64 xyz[18] = {0};
     (void)shard_exchange(ctx, sh, xyz, 0);
   }
@@ -446,9 +452,27 @@ static int commit_batch(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, const 
 }
 
 // The ranks' SRS slices must tile [0, n): a gap or an overlap would give a well-formed but wrong commitment that no
-// rank can see.  One extra exchange per key: every rank contributes len * G and (sum of its coefficient indices) * G
-// (G the group generator, small host-side scalar multiplications); the sums must be n * G and n (n - 1) / 2 * G.
-static pm::host::XYZZ host_mul_generator(u64 k) {
+// rank can see.  One extra exchange per key: every rank contributes len * G and S_rank * G with
+//     S_rank = sum over its coefficient indices i of rho^i      (G the group generator, host-side scalar multiplications),
+// rho a fixed element of Fr of no special structure; the folded sums must be n * G and (rho^n - 1) / (rho - 1) * G.
+// sum_ranks S_rank is the polynomial  sum_i m_i X^i  at rho, m_i = how many ranks hold coefficient i: it equals
+// 1 + X + ... + X^(n-1) as a polynomial exactly when every m_i is 1, and two different polynomials of degree < 2^32
+// agree at a point that was fixed without looking at them with probability < 2^-220 -- this is a guard against
+// mis-configured ranks, not against an adversary.  (r03 compared two moments, count and index sum: slices shifted
+// symmetrically about a centre passed both)
+static const u64 COVER_RHO[4] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL, 0x94d049bb133111ebULL, 0x2545f4914f6cdd1dULL};
+static HFr cover_rho() {                      // the 254-bit constant above (< r), into Montgomery form
+  HFr raw, r2;
+  memcpy(raw.l, COVER_RHO, 32);
+  memcpy(r2.l, FRF().r2, 32);
+  return fmul(raw, r2);
+}
+// sum_{i = lo}^{lo + cnt - 1} rho^i = rho^lo (rho^cnt - 1) / (rho - 1)
+static HFr cover_sum(u64 lo, u64 cnt) {
+  const HFr rho = cover_rho();
+  return fmul(fmul(fpow(rho, lo), fsub(fpow(rho, cnt), fone())), finv(fsub(rho, fone())));
+}
+static pm::host::XYZZ host_mul_generator(const u64 k[4]) {
   using namespace pm::host;
   // the BLS12-381 G1 generator, canonical limbs -> Montgomery
   static const u64 GX[6] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL,
@@ -466,12 +490,17 @@ static pm::host::XYZZ host_mul_generator(u64 k) {
   g.zz = one(F);
   g.zzz = one(F);
   XYZZ acc = xyzz_identity();
-  for (int bit = 63; bit >= 0; --bit) {
+  for (int bit = 255; bit >= 0; --bit) {
     acc = xyzz_double(acc);
-    if ((k >> bit) & 1) acc = xyzz_add(acc, g);
+    if ((k[bit >> 6] >> (bit & 63)) & 1) acc = xyzz_add(acc, g);
   }
   return acc;
 }
+static pm::host::XYZZ host_mul_generator(u64 k) {
+  const u64 kk[4] = {k, 0, 0, 0};
+  return host_mul_generator(kk);
+}
+static pm::host::XYZZ host_mul_generator(const HFr& k) { return host_mul_generator(fr_canonical(k).l); }
 static void host_to_projective(const pm::host::XYZZ& p, u64 out[18]) {
   pm::host::HFp x, y;
   memset(out, 0, 144);
@@ -486,12 +515,11 @@ static void host_to_projective(const pm::host::XYZZ& p, u64 out[18]) {
 static int check_slice_cover(pm_ctx* ctx, const pm_bases* ck, const Shard& sh, size_t n) {
   const size_t have = pm_g1_bases_len(ck);
   const u64 cnt = sh.lo < n ? std::min<size_t>(have, n - sh.lo) : 0;
-  const u64 idx_sum = cnt * (u64)sh.lo + (cnt ? cnt * (cnt - 1) / 2 : 0);
   u64 xyz[2 * 18], want[2 * 18], got_xy[2 * 12], want_xy[2 * 12];
   host_to_projective(host_mul_generator(cnt), xyz);
-  host_to_projective(host_mul_generator(idx_sum), xyz + 18);
+  host_to_projective(host_mul_generator(cover_sum(sh.lo, cnt)), xyz + 18);
   host_to_projective(host_mul_generator((u64)n), want);
-  host_to_projective(host_mul_generator((u64)n * (n - 1) / 2), want + 18);
+  host_to_projective(host_mul_generator(cover_sum(0, n)), want + 18);
   PK_TRY(shard_exchange(ctx, sh, xyz, 2));
   PK_TRY(pm_g1_to_affine_batch(xyz, 2, got_xy, nullptr));
   PK_TRY(pm_g1_to_affine_batch(want, 2, want_xy, nullptr));
@@ -541,6 +569,7 @@ extern "C" int pm_plonk_key_commit_sharded(pm_ctx* ctx, pm_prover_key* key, cons
   sh.lo = first_coefficient;
   sh.fn = exchange;
   sh.user = user;
+  sh.expect = 3;
   return key_commit_impl(ctx, key, commit_key_slice, sh, transcript_label, verifier_key_out);
 }
 
@@ -602,6 +631,7 @@ extern "C" int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* pk, const pm_b
   sh.lo = first_coefficient;
   sh.fn = exchange;
   sh.user = user;
+  sh.expect = 4;
   return prove_impl(ctx, pk, ck_slice, sh, d_witness, pi_positions, pi_values, n_pi, flags, out);
 }
 
@@ -628,6 +658,7 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   if (!ctx || !pk || !ck || !d_witness || !out) return PM_ERR_BAD_ARG;
   if (n_pi && (!pi_positions || !pi_values)) return PM_ERR_BAD_ARG;
   if (flags & ~(PM_PLONK_BIND_PUBLIC_INPUTS | PM_PLONK_UPSTREAM_TRANSCRIPT)) return PM_ERR_BAD_ARG;
+  if (flags == (PM_PLONK_BIND_PUBLIC_INPUTS | PM_PLONK_UPSTREAM_TRANSCRIPT)) return PM_ERR_BAD_ARG;   // the two modes exclude each other
   if (!pk->committed) return PM_ERR_BAD_ARG;   // pm_plonk_key_commit first: the transcript starts from the verifier key
   BusyGuard guard(pk);
   if (!guard.ok) return PM_ERR_BUSY;

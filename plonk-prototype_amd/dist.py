@@ -47,6 +47,29 @@ def allgather_fold(partial_xyz: np.ndarray, device=None) -> np.ndarray:
 _MAX_PARTIALS = 16
 
 
+def _fold_messages(stacked: np.ndarray, mine_failed: bool, empty):
+    """[world, 1 + 288] gathered messages -> [k, 18] folded sums, or None when any rank sent the abort marker
+    or the ranks are out of step (the same rule as the library's ``fold_gathered``, csrc/comm.hip)."""
+    counts = stacked[:, 0]
+    if mine_failed or (counts == 0).any() or (counts != counts[0]).any():
+        return None
+    world, k = stacked.shape[0], int(counts[0])
+    pts = stacked[:, 1:1 + 18 * k].reshape(world, k, 18)
+    return np.stack([g1_fold(np.ascontiguousarray(pts[:, j])) for j in range(k)]) if k else empty
+
+
+def _message(partials_xyz) -> np.ndarray:
+    """The fixed-size exchange message [count | 16 x 18 limbs]; ``None`` -> the abort marker (count 0)."""
+    msg = np.zeros(1 + 18 * _MAX_PARTIALS, np.uint64)
+    if partials_xyz is not None:
+        p = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
+        if p.shape[0] > _MAX_PARTIALS:
+            raise ValueError("at most 16 partial points per exchange")
+        msg[0] = p.shape[0]
+        msg[1:1 + p.size] = p.reshape(-1)
+    return msg
+
+
 def allgather_fold_many(partials_xyz, device=None):
     """[k, 18] partial points per rank -> [k, 18] folded sums, one all_gather for all k (k <= 16).
 
@@ -62,24 +85,67 @@ def allgather_fold_many(partials_xyz, device=None):
         p = np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None if partials_xyz is None else p
-    if p.shape[0] > _MAX_PARTIALS:
-        raise ValueError("at most 16 partial points per exchange")
     world = dist.get_world_size()
-    msg = np.zeros(1 + 18 * _MAX_PARTIALS, np.uint64)
-    msg[0] = 0 if partials_xyz is None else p.shape[0]
-    msg[1:1 + p.size] = p.reshape(-1)
-    mine = torch.from_numpy(msg.view(np.int64).copy())
+    mine = torch.from_numpy(_message(partials_xyz).view(np.int64).copy())
     if device is not None:
         mine = mine.to(device)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     stacked = torch.stack(parts).cpu().numpy().view(np.uint64)          # [world, 1 + 288]
-    counts = stacked[:, 0]
-    if partials_xyz is None or (counts == 0).any() or (counts != counts[0]).any():
-        return None
-    k = int(counts[0])
-    pts = stacked[:, 1:1 + 18 * k].reshape(world, k, 18)
-    return np.stack([g1_fold(np.ascontiguousarray(pts[:, j])) for j in range(k)]) if k else p
+    return _fold_messages(stacked, partials_xyz is None, p)
+
+
+class LocalGroup:
+    """W ranks as THREADS of one process, one :class:`Context` each: the exchange steps of the sharded prover
+    (all-gather + fold of partial points) and of the four-step NTT (all-to-all of blocks) carried by a barrier
+    and shared memory instead of a process group.  Two uses: a host that drives the GPUs of a node from one
+    process (context r on device r; the all-to-all is then a peer copy per block), and the world-size-8
+    rehearsal on a ONE-GPU box, whose process guard allows six GPU processes -- eight gloo ranks cannot run
+    there, eight threads can (tests/test_gpu_world8.py).  Same fixed-size message, same abort marker and the
+    same fold rule as the torch.distributed and the in-library RCCL exchanges."""
+
+    def __init__(self, world: int, timeout: float = 600.0):
+        import threading
+        self.world = world
+        self._barrier = threading.Barrier(world, timeout=timeout)
+        self._msgs = np.zeros((world, 1 + 18 * _MAX_PARTIALS), np.uint64)
+        self._send = [None] * world
+
+    def allgather_fold_many(self, rank: int, partials_xyz):
+        """``allgather_fold_many`` among the threads of the group (``partials_xyz=None`` = abort marker)."""
+        p = np.zeros((0, 18), np.uint64) if partials_xyz is None else \
+            np.ascontiguousarray(partials_xyz, dtype=np.uint64).reshape(-1, 18)
+        self._msgs[rank] = _message(partials_xyz)
+        self._barrier.wait()                       # every message is in place
+        stacked = self._msgs.copy()
+        self._barrier.wait()                       # every rank has its copy: the slots may be overwritten
+        return _fold_messages(stacked, partials_xyz is None, p)
+
+    def alltoall_fn(self, rank: int, stage):
+        """ALLTOALL_FN for ``pm_fr_ntt_fourstep_dev``: ``stage`` is this rank's [2 blk, 4] tensor (send | recv);
+        recv block p = block `rank` of rank p's send half (a peer-to-peer copy per block on a node)."""
+        import torch
+        blk = stage.shape[0] // 2
+        send, recv = stage[:blk], stage[blk:]
+        per = blk // self.world
+
+        def cb(_user, d_send, d_recv, _bytes_per_peer):
+            try:
+                ok = d_send == send.data_ptr() and d_recv == recv.data_ptr()
+                self._send[rank] = send if ok else None
+                self._barrier.wait()
+                peers = list(self._send)
+                if any(s is None for s in peers):
+                    ok = False
+                else:
+                    for p_, s in enumerate(peers):
+                        recv[p_ * per:(p_ + 1) * per].copy_(s[rank * per:(rank + 1) * per])
+                    torch.cuda.synchronize(stage.device)
+                self._barrier.wait()               # the peers have read this rank's send half
+                return 0 if ok else 1
+            except Exception:                      # never raise through the C frame (a broken barrier included)
+                return 1
+        return _lib.ALLTOALL_FN(cb)
 
 
 class ShardedCommitKey:
@@ -88,17 +154,46 @@ class ShardedCommitKey:
     `total`.  ``commit_batch_dev`` runs the local slice of every MSM, then one all_gather + fold."""
 
     def __init__(self, powers_slice, lo: int, total: int, ctx: Context, device=None, precompute: bool = False,
-                 native: bool = False):
+                 native: bool = False, group: "LocalGroup | None" = None, rank: int = 0):
         """native: exchange through the library's own RCCL communicator (``Context.comm_init`` first) instead
-        of torch.distributed -- what a host without PyTorch does."""
+        of torch.distributed -- what a host without PyTorch does.  group / rank: the ranks are threads of this
+        process (:class:`LocalGroup`).  powers_slice: affine points [len, 12], or a ready ``Bases``."""
         self.ctx, self.lo, self.total, self.device, self.native = ctx, lo, total, device, native
-        self._bases = Bases(ctx, powers_slice)
+        self.group, self.rank = group, rank
+        self._bases = powers_slice if isinstance(powers_slice, Bases) else Bases(ctx, powers_slice)
         if precompute and self._bases.n:
             self._bases.precompute()
         one = np.array([0x760900000002FFFD, 0xEBF4000BC40C0002, 0x5F48985753C758BA, 0x77CE585370525745,
                         0x5C071A97A256EC6D, 0x15F65EC3FA80E493], dtype=np.uint64)   # Fp Montgomery 1
         self._identity = np.zeros(18, np.uint64)
         self._identity[6:12] = one
+
+    @classmethod
+    def setup(cls, total: int, tau_int: int, lo: int, hi: int, ctx: Context, **kw) -> "ShardedCommitKey":
+        """This rank's slice tau^lo G .. tau^(hi-1) G of ``PublicParameters::setup``'s commit key, generated on
+        its GPU (``CommitKey.setup`` with the powers started at tau^lo).  tau_int: the trapdoor as an integer --
+        tests and benchmarks only, as upstream's ``setup`` is."""
+        from .field import R_MOD, fr_to_limbs
+        from .host import G1_GENERATOR, DeviceVector, _p
+        cnt = hi - lo
+        powers = DeviceVector(ctx, cnt)
+        pts = DeviceVector(ctx, 3 * cnt)
+        try:
+            ctx.fr_powers(fr_to_limbs(tau_int % R_MOD), fr_to_limbs(pow(tau_int, lo, R_MOD)), cnt, powers.ptr)
+            ctx._check(ctx._lib.pm_g1_fixed_base_mul_dev(ctx._h, _p(G1_GENERATOR), powers._p, cnt,
+                                                         _lib.SCALAR_MONTGOMERY, pts._p, None))
+            bases = Bases.from_device(ctx, pts.ptr, cnt)
+        finally:
+            pts.free()
+            powers.free()
+        return cls(bases, lo, total, ctx, **kw)
+
+    def gather_fold(self, partials_xyz):
+        """One exchange: [k, 18] partial points (None = abort marker) -> the sums over all ranks, or None when a
+        rank gave up.  The transport is whatever this key was built for."""
+        if self.group is not None:
+            return self.group.allgather_fold_many(self.rank, partials_xyz)
+        return allgather_fold_many(partials_xyz, self.device)
 
     def max_degree(self) -> int:
         return self.total - 1
@@ -111,7 +206,7 @@ class ShardedCommitKey:
             part = self._bases.msm_batch_dev(d_ptr + 32 * self.lo, cnt, batch, stride=stride if stride is not None else n)
         else:
             part = np.tile(self._identity, (batch, 1))
-        folded = self.ctx.g1_allgather_fold(part) if self.native else allgather_fold_many(part, self.device)
+        folded = self.ctx.g1_allgather_fold(part) if self.native else self.gather_fold(part)
         if folded is None:
             raise Error(_lib.PM_ERR_EXCHANGE, "a peer rank gave up")
         return [g1_to_affine(p)[0] for p in folded]

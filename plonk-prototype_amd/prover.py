@@ -169,17 +169,15 @@ def preprocess(circuit: Circuit, ctx: Context, ck=None, label: bytes = b"plonk")
 
 
 def _exchange_callback(ck):
-    """pm_exchange_fn over torch.distributed: all-gather the k partial points, fold with the group law.
+    """pm_exchange_fn over the key's transport (torch.distributed, or the threads of a LocalGroup): all-gather the k partial points, fold with the group law.
     k = 0 marks a rank that failed locally: the marker is exchanged so that no rank blocks."""
-    from .dist import allgather_fold_many
-
     def exchange(_user, xyz, k):
         try:
             if k == 0:
-                allgather_fold_many(None, ck.device)
+                ck.gather_fold(None)
                 return 1
             buf = np.ctypeslib.as_array(xyz, shape=(k, 18))
-            res = allgather_fold_many(buf.copy(), ck.device)
+            res = ck.gather_fold(buf.copy())
             if res is None:          # a peer gave up
                 return 1
             buf[:] = res

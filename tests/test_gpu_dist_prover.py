@@ -84,7 +84,7 @@ def test_sharded_prover_world2_equals_single_gpu(ctx):
 
 def _failing_worker(rank, world, port, q, mode):
     """mode "pi": rank 1 passes a public-input position outside the circuit (an argument error on ONE rank, far from
-    any MSM); mode "gap": rank 1's slice starts one coefficient late.  No rank may block: both must get an error."""
+    any MSM); mode "gap": rank 1's slice starts one coefficient late; mode "overlap": both ranks hold the middle half.  No rank may block: both must get an error."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -97,8 +97,10 @@ def _failing_worker(rank, world, port, q, mode):
         ctx = pa.Context(0)
         lo, hi = shard_range(N, rank, world)
         codes = []
-        if mode == "gap":
+        if mode in ("gap", "overlap"):
             shift = 1 if rank == 1 else 0
+            if mode == "overlap":            # both ranks hold [n/4, 3n/4): counts and index sums still add up
+                lo, hi, shift = N // 4, 3 * N // 4, 0
             ck = ShardedCommitKey(srs[lo + shift:hi], lo + shift, N, ctx)
             try:
                 pa.preprocess(circuit, ctx, ck)
@@ -125,7 +127,7 @@ def _failing_worker(rank, world, port, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["pi", "gap"])
+@pytest.mark.parametrize("mode", ["pi", "gap", "overlap"])
 def test_one_rank_failing_outside_an_msm_does_not_block_its_peer(mode):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
@@ -138,7 +140,7 @@ def test_one_rank_failing_outside_an_msm_does_not_block_its_peer(mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    if mode == "gap":
+    if mode in ("gap", "overlap"):
         assert res[0] == [-6] and res[1] == [-6]            # PM_ERR_LENGTH on every rank: the slices do not tile [0, n)
     else:
         assert res[1][0] == -6 and res[0][0] == -7          # the bad rank: PM_ERR_LENGTH; its peer: PM_ERR_EXCHANGE
