@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -369,32 +370,100 @@ __global__ void __launch_bounds__(128) msm_accumulate_ln_kernel(const AccArgs a)
 }
 
 // ------------------------------------------------------------------ 4: bucket reduce
-static constexpr u32 GROUP = 32;   // items per wave in the reduction: one per lane PAIR (ec.hip.h, struct Half)
-// sum_b (b + 1) B_b for every bucket set, as a hierarchy of wave-level reductions with NO per-thread scalar
-// multiple (r01 / early r02: each thread finished its chunk with (chunk offset) x (chunk sum)), and with every
-// point held by a PAIR of lanes (struct Half in ec.hip.h: 7 field-product rounds per addition instead of 14).
-// These kernels run one or two waves per SIMD with long dependent chains, and a lone wave issues one VALU
-// instruction per ~7 cycles: halving the instructions per group operation is what shortens them.
-//   level 1 (msm_bucket_wave_kernel): a lane pair takes `lb` consecutive buckets with the two running sums
+// sum_b (b + 1) B_b for every bucket set (SURVEY CS-4: "running = 0; for b in buckets.rev() { running += b; acc += running }"),
+// as a hierarchy of wave-level reductions whose index weights are never multiplied out on the device.  Every point is
+// held by a PAIR of lanes (struct Half in ec.hip.h: 7 field-product rounds per addition instead of 14).
+//
+// What shaped it (r04, profiles/r04_bucket_reduce_stamps.txt -- in-kernel clock stamps of the r03 kernel): two waves that
+// share a SIMD do NOT share its issue slots -- the older wave runs at the speed of a lone wave (~5 cycles per VALU
+// instruction for this code, whatever the number of dependency chains), the younger one gets ~10 % and only starts
+// properly when the older has left; and single-wave workgroups are not spread evenly over the SIMDs.  So the reduction
+// runs ONE wave per SIMD, placed exactly (four-wave workgroups, one per CU: a workgroup's waves go to the CU's four
+// SIMDs, and its LDS request keeps a second workgroup out), and what a wave does after its buckets is five dependent
+// additions instead of fifteen:
+//   level 1 (msm_bucket_reduce_kernel): a lane pair takes `lb` consecutive buckets with the running sums
 //       S = sum B,  T = sum (i + 1) B_i,  so its chunk t = 32 w + l contributes T + lb t S.
-//       Across the 32 pairs of the wave: the suffix scan P_l = sum_{l' >= l} S_l' (5 additions) gives
-//       sum_l l S_l = sum_{l >= 1} P_l and W_w = P_0, so the wave writes
-//           a_w = sum_l (T_l + lb [l >= 1] P_l)       (log2 lb doublings, one addition, a 5-step tree)
-//           W_w = sum_l S_l
-//       and the set's total is  sum_w (a_w + 32 lb w W_w).
-//   level k >= 2 (msm_level_kernel): 32 consecutive items per wave.  Sequences that only need adding up
-//       (a, and the index-weighted sums v of the earlier levels) get a 5-step tree each; the sequence W is
-//       scanned and summed as above and yields v' = sum_l l W_l and W' = sum_l W_l for the next level.
-//       Independent waves (blockIdx.y) take the independent jobs.
-//   The last level leaves  F_0 = sum a,  F_1 .. F_L  (v of level 2 .. L + 1) per set; the powers of two that
-//   belong to them (32 lb, 32^2 lb, ..) are applied in the host fold, where a doubling costs well under 1 us.
-//   Levels run on the device until at most four items per set are left; the host fold does that last level itself.
-__global__ void __launch_bounds__(64, 2) msm_bucket_wave_kernel(const u32x4* buckets, u32 nbuckets, u32 lb, u32 log_lb,
-                                                                u32 n1, u32 finalize, u32x4* out_a, u32x4* out_w) {
-  const u32 set = blockIdx.x / n1, w = blockIdx.x % n1;
-  const u32 pi = threadIdx.x >> 1;          // the pair's index in the wave: 32 chunks per wave
+//       The 32 pairs of the wave are then combined by a BUTTERFLY through LDS (wave_butterfly): after step j every
+//       block of 2^j lanes holds  A = sum S,  Tt = sum T  and the BIT PLANES  p_k = sum_{l : bit k of l} S_l  (k < j) --
+//       merging two blocks is one addition per value, all of them on different lane pairs of the block (j + 1 <= 2^j),
+//       and the new plane p_(j-1) is the right block's A: a copy.  Five steps leave  W_w = sum_l S_l,  Tt_w  and
+//       p_0 .. p_4 with  sum_l l S_l = sum_k 2^k p_k  -- no scan, no doubling, no second tree.
+//       The set's total is  sum_w Tt_w + lb sum_k 2^k sum_w p_{k,w} + 32 lb sum_w w W_w.
+//   level k >= 2 (msm_reduce_level_kernel): 32 consecutive items per wave.  Sequences that only need adding up (Tt and
+//       every plane of the earlier levels) get a 5-step tree each; the sequence W goes through the same butterfly and
+//       yields five more planes (the next five bits of the chunk index) and W'.  Independent waves take the jobs.
+//   The host receives  Tt,  the planes Q_0 .. Q_(5 L - 1)  (bit b of the chunk index) and at most four items of the last
+//   W, and evaluates  Tt + lb (sum_b 2^b Q_b + 32^L sum_l l W_l)  by Horner's rule: a doubling costs well under 1 us there.
+static constexpr u32 GROUP = 32;                 // items per wave in the reduction: one per lane PAIR (ec.hip.h, struct Half)
+static constexpr u32 PLANES = 5;                 // log2 GROUP: bit planes one butterfly leaves
+static constexpr u32 RED_SLOTS = 2 * GROUP + 48; // 256-byte LDS records per wave: the butterfly's two buffers (64 + 16 x 3)
+static constexpr u32 RED_WAVES = 4;              // waves per workgroup in level 1: one per SIMD of the CU
+
+// LDS traffic of ONE wave: its DS operations execute in order, so a read sees the wave's earlier writes; the fences
+// only keep the compiler from moving them across the step boundary.
+PM_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// On entry lane pair `pi` holds S (and T when HAS_T).  Returns the buffer whose records 0 .. 6 hold
+//   W = sum S,  Tt = sum T,  p_0 .. p_4  (p_k = sum of S over the lane pairs whose bit k is set).
+// State after step j, in LDS: block b (2^j lane pairs) owns records b (j + 2) .. : A, Tt, p_0 .. p_(j-1).
+template <bool HAS_T>
+PM_DEV const u32x4* wave_butterfly(u32x4* lds, u32 pi, bool isB, const Half& S, const Half& T) {
+  u32x4* bufs[2] = {lds, lds + 2 * GROUP * 16};
+  st_half(bufs[0], 2 * pi, S, isB);
+  st_half(bufs[0], 2 * pi + 1, T, isB);
+  wave_lds_sync();
+#pragma unroll
+  for (u32 j = 1; j <= PLANES; ++j) {
+    const u32x4* src = bufs[(j - 1) & 1];
+    u32x4* dst = bufs[j & 1];
+    const u32 b = pi >> j, o = pi & ((1u << j) - 1u);
+    const u32 nv = j + 1;                                   // values per child block
+    const u32 L = 2 * b * nv, R = L + nv, D = b * (nv + 1);
+    if (o < nv) {
+      if (HAS_T || o != 1) {
+        const Half x = ld_half(src, L + o, isB), y = ld_half(src, R + o, isB);
+        st_half(dst, D + o, half_add(x, y, isB), isB);
+      } else {
+        st_half(dst, D + o, half_identity(), isB);
+      }
+    }
+    if (o == (j == 1 ? 0u : nv)) st_half(dst, D + nv, ld_half(src, R, isB), isB);   // p_(j-1) = A of the right block
+    wave_lds_sync();
+  }
+  return bufs[PLANES & 1];
+}
+// butterfly record -> output sequence: sequences are [Tt | planes ... | W]; `first_plane` = index of this level's p_0
+PM_DEV u32 red_seq_of(u32 rec, u32 first_plane, u32 w_seq) { return rec == 0 ? w_seq : (rec == 1 ? 0u : first_plane + rec - 2); }
+
+// Diagnostic build only (make EXTRA=-DPM_DEV_STAMPS, tools/ab_reduce.sh): every wave leaves shader-clock and
+// wall-clock stamps at its phase boundaries, from which the host prints the waves' start / end skew, the phase
+// lengths and the in-kernel clock.  The product build has none of it.
+#ifdef PM_DEV_STAMPS
+__device__ unsigned long long* g_bucket_stamps = nullptr;
+#define BUCKET_STAMP(k)                                                                       \
+  if (g_bucket_stamps && (threadIdx.x & 63u) == 0) {                                          \
+    g_bucket_stamps[(size_t)widx * 16 + 2 * (k)] = __builtin_amdgcn_s_memtime();              \
+    g_bucket_stamps[(size_t)widx * 16 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();      \
+  }
+#else
+#define BUCKET_STAMP(k)
+#endif
+// out: 7 sequences of n_waves records ([Tt | p_0 .. p_4 | W], seq_stride u32x4 apart), record index = the wave's index
+__global__ void __launch_bounds__(64 * RED_WAVES, 1)
+    msm_bucket_reduce_kernel(const u32x4* buckets, u32 nbuckets, u32 lb, u32 n1, u32 n_waves, u32 finalize, u32x4* out,
+                             size_t seq_stride) {
+  extern __shared__ u32x4 red_lds[];
+  const u32 wv = threadIdx.x >> 6;
+  const u32 widx = blockIdx.x * RED_WAVES + wv;   // this wave's item: (set, w)
+  if (widx >= n_waves) return;                    // whole waves only, and no workgroup barrier below
+  BUCKET_STAMP(0);
+  const u32 set = widx / n1, w = widx % n1;
+  const u32 pi = (threadIdx.x & 63u) >> 1;        // the pair's index in the wave: 32 chunks per wave
   const bool isB = threadIdx.x & 1;
-  const u32 nt = nbuckets / lb;  // chunks per set
+  const u32 nt = nbuckets / lb;                   // chunks per set
   const u32 t = GROUP * w + pi;
   Half running = half_identity(), sum = half_identity();
   if (t < nt) {
@@ -405,77 +474,91 @@ __global__ void __launch_bounds__(64, 2) msm_bucket_wave_kernel(const u32x4* buc
       sum = half_add(sum, running, isB);
     }
   }
-  for (int d = 1; d < (int)GROUP; d <<= 1) {
-    Half o = half_shfl_down(running, d);
-    if (pi + d < GROUP) running = half_add(running, o, isB);
+  BUCKET_STAMP(1);
+  const u32x4* res = wave_butterfly<true>(red_lds + (size_t)wv * RED_SLOTS * 16, pi, isB, running, sum);
+  BUCKET_STAMP(2);
+  if (pi < PLANES + 2) {
+    Half v = ld_half(res, pi, isB);
+    if (finalize && !v.inf) v.c0 = fe_mul<FpP>(v.c0, fe_one<FpP>());   // the host needs x, y that fit 384 bits
+    st_half(out + red_seq_of(pi, 1, PLANES + 1) * seq_stride, widx, v, isB);
   }
-  if (pi == 0) {
-    Half wsum = running;
-    if (finalize && !wsum.inf) wsum.c0 = fe_mul<FpP>(wsum.c0, fe_one<FpP>());
-    st_half(out_w, blockIdx.x, wsum, isB);
-    running = half_identity();
-  }
-  for (u32 k = 0; k < log_lb; ++k) running = half_double(running, isB);
-  sum = half_add(sum, running, isB);
-  for (int d = GROUP / 2; d > 0; d >>= 1) {   // pairs >= d would add their own value to itself (the slow P + P path)
-    Half o = half_shfl_down(sum, d);
-    if (pi < (u32)d) sum = half_add(sum, o, isB);
-  }
-  if (pi == 0) {
-    if (finalize && !sum.inf) sum.c0 = fe_mul<FpP>(sum.c0, fe_one<FpP>());   // the host needs x, y that fit 384 bits
-    st_half(out_a, blockIdx.x, sum, isB);
-  }
+  BUCKET_STAMP(3);
 }
 
-struct LevelArgs {
-  const u32x4* plain_in0;   // sequences to add up: per set n_items entries
-  const u32x4* plain_in1;
-  const u32x4* plain_in2;
-  u32x4* plain_out0;        // per set n_groups entries
-  u32x4* plain_out1;
-  u32x4* plain_out2;
-  const u32x4* w_in;        // the sequence W: scanned
-  u32x4* v_out;             // sum_l l W_l per group
-  u32x4* w_out;             // sum_l W_l per group
-  u32 n_plain;
+// in: n_seq_in sequences of n_items records per set ([Tt | planes | W]); out: n_seq_in + 5 sequences of n_groups records
+struct RedLevelArgs {
+  const u32x4* in;
+  u32x4* out;
+  size_t in_stride, out_stride;   // u32x4 per sequence
+  u32 n_seq_in;
   u32 n_items;
-  u32 n_groups;             // ceil(n_items / GROUP)
+  u32 n_groups;                   // ceil(n_items / GROUP)
   u32 finalize;
 };
-__global__ void __launch_bounds__(64, 2) msm_level_kernel(const LevelArgs a) {
+__global__ void __launch_bounds__(64, 2) msm_reduce_level_kernel(const RedLevelArgs a) {
+  __shared__ u32x4 lds[RED_SLOTS * 16];
   const u32 set = blockIdx.x / a.n_groups, g = blockIdx.x % a.n_groups, job = blockIdx.y;
   const u32 pi = threadIdx.x >> 1;
   const bool isB = threadIdx.x & 1;
   const u32 idx = GROUP * g + pi;
-  const bool live = idx < a.n_items;
   const size_t src = (size_t)set * a.n_items + idx;
   Half acc = half_identity();
-  u32x4* out;
-  if (job < a.n_plain) {
-    const u32x4* in = job == 0 ? a.plain_in0 : (job == 1 ? a.plain_in1 : a.plain_in2);
-    out = job == 0 ? a.plain_out0 : (job == 1 ? a.plain_out1 : a.plain_out2);
-    if (live) acc = ld_half(in, src, isB);
-  } else {
-    out = a.v_out;
-    if (live) acc = ld_half(a.w_in, src, isB);
-    for (int d = 1; d < (int)GROUP; d <<= 1) {
+  if (idx < a.n_items) acc = ld_half(a.in + job * a.in_stride, src, isB);
+  if (job + 1 < a.n_seq_in) {   // a sequence that only needs adding up
+    for (int d = GROUP / 2; d > 0; d >>= 1) {   // pairs >= d would add their own value to itself (the slow P + P path)
       Half o = half_shfl_down(acc, d);
-      if (pi + d < GROUP) acc = half_add(acc, o, isB);
+      if (pi < (u32)d) acc = half_add(acc, o, isB);
     }
     if (pi == 0) {
-      Half wsum = acc;
-      if (a.finalize && !wsum.inf) wsum.c0 = fe_mul<FpP>(wsum.c0, fe_one<FpP>());
-      st_half(a.w_out, blockIdx.x, wsum, isB);
-      acc = half_identity();
+      if (a.finalize && !acc.inf) acc.c0 = fe_mul<FpP>(acc.c0, fe_one<FpP>());
+      st_half(a.out + job * a.out_stride, blockIdx.x, acc, isB);
     }
+    return;
   }
+  // the sequence W: five more planes of the chunk index, and W'
+  const u32x4* res = wave_butterfly<false>(lds, pi, isB, acc, half_identity());
+  if (pi < PLANES + 2 && pi != 1) {
+    Half v = ld_half(res, pi, isB);
+    if (a.finalize && !v.inf) v.c0 = fe_mul<FpP>(v.c0, fe_one<FpP>());
+    st_half(a.out + red_seq_of(pi, a.n_seq_in - 1, a.n_seq_in + PLANES - 1) * a.out_stride, blockIdx.x, v, isB);
+  }
+}
+
+// What the host fold would do per set -- Tt + lb (sum_b 2^b Q_b + 32^L sum_l l W_l) -- for launches with MANY sets (a
+// table-free MSM has one set per window, a batch one per vector and window): one wave per set, one lane pair per term.
+// Pair q sums its sequence over the host_items items (the W sequence appears twice, once per bit of the item index: its
+// two bit planes), doubles the sum e(q) times -- every pair in lock step, the pairs with small exponents idle -- and the
+// terms are added up by a 5-step tree.  A chain of ~3 + e_max + 5 operations (~0.15-0.2 ms) whatever the number of
+// sets, against ~40 us of host arithmetic per set (host additions ~1 us, doublings ~0.65 us: tools/host_field_bench.cpp).
+__global__ void __launch_bounds__(64, 2) msm_reduce_finish_kernel(const u32x4* in, size_t in_stride, u32 n_sets, u32 host_items,
+                                                                  u32 nplanes, u32 log_lb, u32x4* out) {
+  const u32 set = blockIdx.x;
+  const u32 pi = threadIdx.x >> 1;
+  const bool isB = threadIdx.x & 1;
+  // term q: 0 = Tt (weight 1), 1 .. nplanes = plane q - 1 (weight lb 2^(q-1)), then bit planes 0 and 1 of the W items
+  u32 seq = 0, mask = 0, e = 0;
+  const u32 all = (1u << host_items) - 1u;
+  if (pi == 0) {
+    mask = all;
+  } else if (pi <= nplanes) {
+    seq = pi, mask = all, e = log_lb + pi - 1;
+  } else if (pi <= nplanes + 2 && host_items > 1) {
+    const u32 bit = pi - nplanes - 1;
+    seq = nplanes + 1, mask = all & (bit == 0 ? 0xAu : 0xCu), e = log_lb + nplanes + bit;
+  }
+  Half acc = half_identity();
+  for (u32 l = 0; l < host_items; ++l)
+    if ((mask >> l) & 1u) acc = half_add(acc, ld_half(in + seq * in_stride, (size_t)set * host_items + l, isB), isB);
+  const u32 e_max = log_lb + nplanes + 1;
+  for (u32 k = 0; k < e_max; ++k)
+    if (k < e) acc = half_double(acc, isB);
   for (int d = GROUP / 2; d > 0; d >>= 1) {
     Half o = half_shfl_down(acc, d);
     if (pi < (u32)d) acc = half_add(acc, o, isB);
   }
   if (pi == 0) {
-    if (a.finalize && !acc.inf) acc.c0 = fe_mul<FpP>(acc.c0, fe_one<FpP>());
-    st_half(out, blockIdx.x, acc, isB);
+    if (!acc.inf) acc.c0 = fe_mul<FpP>(acc.c0, fe_one<FpP>());   // the host needs x, y that fit 384 bits
+    st_half(out, set, acc, isB);
   }
 }
 
@@ -587,9 +670,10 @@ static bool msm_debug() {
 // What the host needs to finish one piece of an MSM call (a sub-batch that went through the kernels on its own).
 struct MsmPiece {
   u32 batch, nsets, c, n_dev, host_items, log_lb, nsets_all;
-  const u32* hw;        // pinned host memory: (n_dev + 2) sequences x nsets_all x host_items XYZZ records
+  bool finished;        // the device applied the weights (msm_reduce_finish_kernel): ONE record per set
+  const u32* hw;        // pinned host memory: (7 + 5 n_dev) sequences x nsets_all x host_items XYZZ records
 };
-// One piece: every kernel of the pipeline plus the copy of its (n_dev + 2) x nsets_all x host_items result points, enqueued on
+// One piece: every kernel of the pipeline plus the copy of its (7 + 5 n_dev) x nsets_all x host_items result points, enqueued on
 // `st` -- no host synchronisation.  ws == nullptr: nothing is launched, only *need_ws / *need_pinned are set (bytes of
 // device workspace and of pinned host memory a piece of this shape takes).  front_done (optional) is recorded after the
 // last accumulate level: from there on the piece only reads its own buckets (not the control block of the bucket fill).
@@ -640,34 +724,52 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   }
   const size_t l1_threads = (m + L1 - 1) / L1;
   const size_t total_buckets = (size_t)g.nbuckets * nsets_all;
-  // Buckets per lane pair in level 1 of the reduction (a power of two).  A pair does 2 LB + 11 + log2 LB group
-  // operations and the kernel fits two waves per SIMD (234 VGPRs), so the best LB is the one that fills the chip
-  // once: all buckets of the launch / 2^16 -- 8 for one MSM at 2^19 buckets, 32 for a batch of four -- and 2 for
-  // small sets (an 8-way shard with 2^15 buckets: 1.00 ms with 2, 1.05 ms with 1; profiles/r02_msm_lb.txt).
-  u32 lb_auto = 2;
-  while (lb_auto < 64 && (total_buckets / lb_auto) > ((size_t)ctx->num_cus * 4 * 64)) lb_auto *= 2;
-  // ... and mid-size sets (2^13 .. 2^15 buckets) take up to 8 so that level 1 leaves at most 128 items per set: ONE
-  // follow-up launch (128 -> 4, the host does the rest) instead of two; a launch is a ~100 us chain whatever its size
-  // (profiles/r03_small_msm.txt: batch of four at 2^16 points, 1.35 -> 1.29 ms)
-  while (lb_auto < 8 && g.nbuckets / lb_auto > 128 * GROUP && g.nbuckets / 8 <= 128 * GROUP) lb_auto *= 2;
-  const u32 LB = std::min<u32>(ctx->opt_msm_lb ? (u32)ctx->opt_msm_lb : lb_auto, g.nbuckets);
+  // Buckets per lane pair in level 1 of the reduction (a power of two).  A pair does 2 LB + 5 group operations and the
+  // kernel runs ONE wave per SIMD (section 4 above): waves beyond 4 per CU queue for a second round.  Every further
+  // level is a launch of ~5 dependent operations, and the host fold pays per sequence and item it receives.  LB is the
+  // candidate with the smallest estimate of the three together (us; the constants are measured: profiles/r04_small_msm.txt
+  // -- 2^19 buckets: 16, a batch of four: 64, an 8-way shard's 2^15: 1, four sets of 2^12: 4).
+  // The host takes over when at most HOST_ITEMS items per set are left: a launch that folds two or three items is a
+  // ~55 us chain on one wave, the same fold is a handful of additions (~1 us each) in the host fold below.
+  constexpr u32 HOST_ITEMS = 4;
+  struct RedPlan {
+    u32 lb, n1, host_items;
+    std::vector<u32> groups;
+    double est;
+  };
+  auto red_plan = [&](u32 lb) {
+    RedPlan p;
+    p.lb = lb;
+    p.n1 = (g.nbuckets / lb + GROUP - 1) / GROUP;   // waves per set in level 1
+    p.host_items = p.n1;
+    while (p.host_items > HOST_ITEMS) {
+      p.host_items = (p.host_items + GROUP - 1) / GROUP;
+      p.groups.push_back(p.host_items);
+    }
+    const double waves = (double)p.n1 * nsets_all, slots = (double)ctx->num_cus * RED_WAVES;
+    const double rounds = std::ceil(waves / slots), n_seq = (PLANES + 2) + PLANES * (double)p.groups.size();
+    p.est = rounds * (2.0 * lb + 6.0) * 9.0 + 65.0 * (double)p.groups.size() +
+            (double)nsets_all * n_seq * (0.35 * p.host_items + 0.7 * (p.host_items - 1));
+    return p;
+  };
+  RedPlan plan = red_plan(1);
+  if (ctx->opt_msm_lb) {
+    plan = red_plan(std::min<u32>((u32)ctx->opt_msm_lb, g.nbuckets));
+  } else {
+    for (u32 lb = 2; lb <= 256 && lb <= g.nbuckets; lb *= 2) {
+      RedPlan p = red_plan(lb);
+      if (p.est < plan.est) plan = p;
+    }
+  }
+  const u32 LB = plan.lb;
   u32 log_lb = 0;
   while ((1u << log_lb) < LB) ++log_lb;
-  const u32 chunks_per_win = g.nbuckets / LB;
-  // waves per set in level 1, then the group counts of the follow-up levels (64 items per wave) down to one
-  const u32 n1 = (chunks_per_win + GROUP - 1) / GROUP;
-  // ... down to at most HOST_ITEMS per set: a launch that folds two or three items is a ~55 us chain of ten dependent
-  // operations on one wave, the same fold is a handful of additions (~1 us each) in the host fold below
-  constexpr u32 HOST_ITEMS = 4;
-  std::vector<u32> lvl_groups;
-  u32 host_items = n1;
-  while (host_items > HOST_ITEMS) {
-    host_items = (host_items + GROUP - 1) / GROUP;
-    lvl_groups.push_back(host_items);
-  }
+  const u32 n1 = plan.n1, host_items = plan.host_items;
+  const std::vector<u32>& lvl_groups = plan.groups;   // group counts of the follow-up levels
   const u32 n_dev = (u32)lvl_groups.size();   // follow-up launches
   if (n_dev > 3) return set_err(ctx, PM_ERR_BAD_ARG, "internal: bucket reduction deeper than four levels");
-  // what the host receives: n_dev + 2 sequences (a, the v of every device level, W) of host_items entries per set
+  // what the host receives: 7 + 5 n_dev sequences (Tt, five planes per level, W) of host_items entries per set
+  const u32 n_seq_host = (PLANES + 2) + PLANES * n_dev;
 
   // workspace layout
   size_t off = 0;
@@ -686,13 +788,20 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
     o_ppts[i] = take(lv[i].len * 256);
   }
   const size_t o_heads = take(lv.size() > 1 ? l1_threads * 256 : 0);
-  // level 1 writes (a, W) per wave; level k writes its plain sums, v and W per group; the last level's plain sums
-  // and v go to the slots of o_win (slot j: one point per set, nsets_all points per slot) that the host reads
-  const size_t o_l1a = take((size_t)nsets_all * n1 * 256), o_l1w = take((size_t)nsets_all * n1 * 256);
+  // level 1 writes 7 sequences of one record per wave, every further level 5 sequences more of one record per group;
+  // the last one writes to o_win (sequence-major: nsets_all x host_items records per sequence), which the host reads
+  const size_t o_l1 = take((size_t)(PLANES + 2) * nsets_all * n1 * 256);
   std::vector<size_t> o_lvl(n_dev);
-  for (u32 k = 0; k < n_dev; ++k) o_lvl[k] = take((size_t)(k + 3) * nsets_all * lvl_groups[k] * 256);
-  const size_t o_win = take((size_t)(n_dev + 2) * nsets_all * host_items * 256);
-  const size_t pinned_bytes = (size_t)(n_dev + 2) * nsets_all * host_items * 256;
+  for (u32 k = 0; k < n_dev; ++k) o_lvl[k] = take((size_t)((PLANES + 2) + PLANES * (k + 1)) * nsets_all * lvl_groups[k] * 256);
+  const size_t o_win = take((size_t)n_seq_host * nsets_all * host_items * 256);
+  // Who applies the weights: the host fold (~1 us per addition, ~0.65 us per doubling, per set) or one more launch
+  // (msm_reduce_finish_kernel: a fixed chain whatever the number of sets).  One or a few sets: the host.
+  const u32 nplanes = PLANES * (n_dev + 1);
+  const double fold_host_us = (double)nsets_all * (n_seq_host * (0.3 * host_items + 1.0 * (host_items - 1)) + 1.65 * nplanes);
+  const double fold_dev_us = (host_items + 0.72 * (log_lb + nplanes + 1) + 5.0) * 9.0 + 20.0 + 0.5 * nsets_all;
+  const bool use_finish = fold_host_us > fold_dev_us;
+  const size_t o_fin = take(use_finish ? (size_t)nsets_all * 256 : 0);
+  const size_t pinned_bytes = use_finish ? (size_t)nsets_all * 256 : (size_t)n_seq_host * nsets_all * host_items * 256;
   if (!ws) {
     *need_ws = off;
     *need_pinned = pinned_bytes;
@@ -777,88 +886,133 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
     PM_HIP(ctx, hipGetLastError());
   }
   if (front_done) PM_HIP(ctx, hipEventRecord(front_done, st));
-  // 4 bucket reduce: level 1 over the buckets, then the small levels (see msm_bucket_wave_kernel)
+  // 4 bucket reduce: level 1 over the buckets, then the small levels (see msm_bucket_reduce_kernel)
   u32x4* win = (u32x4*)(ws + o_win);
-  const size_t slot = (size_t)nsets_all * host_items * 16;   // u32x4 per sequence in o_win
+  const u32 n_waves = nsets_all * n1;
+#ifdef PM_DEV_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  if (getenv("PM_MSM_STAMPS")) {
+    if (d_stamps) (void)hipFree(d_stamps);
+    PM_HIP(ctx, hipMalloc(&d_stamps, (size_t)n_waves * 128));
+    PM_HIP(ctx, hipMemsetAsync(d_stamps, 0, (size_t)n_waves * 128, st));
+    PM_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bucket_stamps), &d_stamps, sizeof d_stamps, 0, hipMemcpyHostToDevice, st));
+  }
+#endif
   {
     ProfScope prof(ctx, st, "msm_bucket_chunk");
-    hipLaunchKernelGGL(msm_bucket_wave_kernel, dim3(nsets_all * n1), dim3(64), 0, st, (const u32x4*)buckets, g.nbuckets, LB,
-                       log_lb, n1, n_dev == 0 ? 1u : 0u, n_dev == 0 ? win : (u32x4*)(ws + o_l1a),
-                       n_dev == 0 ? win + slot : (u32x4*)(ws + o_l1w));
+    // four-wave workgroups, ONE per CU (its LDS request keeps a second one out): a wave per SIMD
+    const size_t red_lds = (size_t)RED_WAVES * RED_SLOTS * 256;
+    if (int lrc = raise_lds_limit(ctx, (const void*)msm_bucket_reduce_kernel, red_lds)) return lrc;
+    hipLaunchKernelGGL(msm_bucket_reduce_kernel, dim3((n_waves + RED_WAVES - 1) / RED_WAVES), dim3(64 * RED_WAVES), red_lds, st,
+                       (const u32x4*)buckets, g.nbuckets, LB, n1, n_waves, n_dev == 0 && !use_finish ? 1u : 0u,
+                       n_dev == 0 ? win : (u32x4*)(ws + o_l1), (size_t)n_waves * 16);
   }
   PM_HIP(ctx, hipGetLastError());
+#ifdef PM_DEV_STAMPS
+  if (getenv("PM_MSM_STAMPS") && d_stamps) {
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)n_waves * 16);
+    PM_HIP(ctx, hipMemcpy(h.data(), d_stamps, (size_t)n_waves * 128, hipMemcpyDeviceToHost));
+    const int NPH = 3;
+    unsigned long long r0 = ~0ull, r1 = 0;
+    for (size_t i = 0; i < n_waves; ++i) {
+      r0 = std::min(r0, h[16 * i + 1]);
+      r1 = std::max(r1, h[16 * i + 2 * NPH + 1]);
+    }
+    double sum_c[NPH] = {0}, sum_w[NPH] = {0}, start_sum = 0, end_sum = 0, start_max = 0, end_min = 1e30;
+    for (size_t i = 0; i < n_waves; ++i) {
+      for (int k = 0; k < NPH; ++k) {
+        sum_c[k] += (double)(h[16 * i + 2 * (k + 1)] - h[16 * i + 2 * k]);
+        sum_w[k] += (double)(h[16 * i + 2 * (k + 1) + 1] - h[16 * i + 2 * k + 1]);
+      }
+      const double s0 = (double)(h[16 * i + 1] - r0) / 100.0, e0 = (double)(h[16 * i + 2 * NPH + 1] - r0) / 100.0;
+      start_sum += s0; end_sum += e0;
+      start_max = std::max(start_max, s0); end_min = std::min(end_min, e0);
+    }
+    const double nw = (double)n_waves;   // wall clock: 100 MHz ticks
+    fprintf(stderr, "[stamps] waves %u lb %u  kernel span %.1f us | start mean %.1f max %.1f us | end mean %.1f min %.1f us\n",
+            n_waves, LB, (double)(r1 - r0) / 100.0, start_sum / nw, start_max, end_sum / nw, end_min);
+    static const char* ph[NPH] = {"per-pair", "butterfly", "store"};
+    for (int k = 0; k < NPH; ++k)
+      fprintf(stderr, "[stamps]   %-9s %.1f us  %.0f shader cycles  -> %.3f GHz\n", ph[k], sum_w[k] / nw / 100.0, sum_c[k] / nw,
+              sum_c[k] / (sum_w[k] * 10.0));
+    unsigned hist[11] = {0};
+    for (size_t i = 0; i < n_waves; ++i) hist[(size_t)(10.0 * (double)(h[16 * i + 2 * NPH + 1] - r0) / (double)(r1 - r0))]++;
+    fprintf(stderr, "[stamps]   end-time histogram (tenths of the span):");
+    for (int k = 0; k < 11; ++k) fprintf(stderr, " %u", hist[k]);
+    fprintf(stderr, "\n");
+  }
+#endif
   if (n_dev) {
     ProfScope prof(ctx, st, "msm_window_sum");
-    const u32x4* plain[3] = {(const u32x4*)(ws + o_l1a), nullptr, nullptr};
-    const u32x4* w_in = (const u32x4*)(ws + o_l1w);
-    u32 items = n1;
+    const u32x4* in = (const u32x4*)(ws + o_l1);
+    u32 items = n1, n_seq = PLANES + 2;
     for (u32 k = 0; k < n_dev; ++k) {
-      const u32 groups = lvl_groups[k], n_plain = k + 1;
-      const bool last = k + 1 == n_dev;   // writes the host's sequences: [sequence][set x host_items], fit for conversion
-      const size_t per = (size_t)nsets_all * groups * 16;   // u32x4 per output array of this level
-      u32x4* base = (u32x4*)(ws + o_lvl[k]);
-      LevelArgs la;
-      memset(&la, 0, sizeof la);
-      la.plain_in0 = plain[0]; la.plain_in1 = plain[1]; la.plain_in2 = plain[2];
-      u32x4* pout[3] = {nullptr, nullptr, nullptr};
-      for (u32 j = 0; j < n_plain; ++j) pout[j] = last ? win + j * slot : base + j * per;
-      la.plain_out0 = pout[0]; la.plain_out1 = pout[1]; la.plain_out2 = pout[2];
-      la.w_in = w_in;
-      la.v_out = last ? win + n_plain * slot : base + n_plain * per;
-      la.w_out = last ? win + (n_plain + 1) * slot : base + (n_plain + 1) * per;
-      la.n_plain = n_plain;
+      const u32 groups = lvl_groups[k];
+      const bool last = k + 1 == n_dev;   // writes the host's sequences, fit for conversion
+      RedLevelArgs la;
+      la.in = in;
+      la.out = last ? win : (u32x4*)(ws + o_lvl[k]);
+      la.in_stride = (size_t)nsets_all * items * 16;
+      la.out_stride = (size_t)nsets_all * groups * 16;
+      la.n_seq_in = n_seq;
       la.n_items = items;
       la.n_groups = groups;
-      la.finalize = last ? 1u : 0u;
-      hipLaunchKernelGGL(msm_level_kernel, dim3(nsets_all * groups, n_plain + 1), dim3(64), 0, st, la);
-      for (u32 j = 0; j < n_plain; ++j) plain[j] = pout[j];
-      if (!last) plain[n_plain] = la.v_out;
-      w_in = la.w_out;
+      la.finalize = last && !use_finish ? 1u : 0u;
+      hipLaunchKernelGGL(msm_reduce_level_kernel, dim3(nsets_all * groups, n_seq), dim3(64), 0, st, la);
+      in = la.out;
       items = groups;
+      n_seq += PLANES;
     }
   }
+  if (use_finish) {
+    ProfScope prof(ctx, st, "msm_window_sum");
+    hipLaunchKernelGGL(msm_reduce_finish_kernel, dim3(nsets_all), dim3(64), 0, st, (const u32x4*)win,
+                       (size_t)nsets_all * host_items * 16, nsets_all, host_items, nplanes, log_lb, (u32x4*)(ws + o_fin));
+  }
   PM_HIP(ctx, hipGetLastError());
-  PM_HIP(ctx, hipMemcpyAsync(pinned, ws + o_win, pinned_bytes, hipMemcpyDeviceToHost, st));
+  PM_HIP(ctx, hipMemcpyAsync(pinned, ws + (use_finish ? o_fin : o_win), pinned_bytes, hipMemcpyDeviceToHost, st));
   piece->batch = batch;
   piece->nsets = g.nsets;
   piece->c = g.c;
   piece->n_dev = n_dev;
   piece->host_items = host_items;
+  piece->finished = use_finish;
   piece->log_lb = log_lb;
   piece->nsets_all = nsets_all;
   piece->hw = (const u32*)pinned;
   return PM_OK;
 }
-// 5 host fold of a piece whose copy has arrived.  Per set the device left n_dev + 2 sequences of host_items entries: the
-// plain sums a, v_1 .. v_ndev and the last W.  The host does the last level itself when host_items > 1 (F_j = the sum of
-// sequence j, one more F = sum_l l W_l), then F_0 + 32 LB (F_1 + 32 (F_2 + 32 F_3)), then the windows.
+// 5 host fold of a piece whose copy has arrived.  Per set the device left 7 + 5 n_dev sequences of host_items entries:
+// Tt, the planes Q_0 .. Q_(5 L - 1) (L = n_dev + 1; plane b = the sum of S over the chunks whose index has bit b set) and the
+// last W.  The set's total is  Tt + lb (sum_b 2^b Q_b + 32^L sum_l l W_l),  by Horner's rule from the top.
 static void msm_fold(const MsmPiece& pc, XYZZ* totals) {
   const u32* hw = pc.hw;
   auto entry = [&](u32 seq, size_t set, u32 item) {
     return xyzz_to_host(hw + 64 * (((size_t)seq * pc.nsets_all + set) * pc.host_items + item));
   };
+  auto seq_sum = [&](u32 seq, size_t set) {
+    XYZZ f = entry(seq, set, 0);
+    for (u32 l = 1; l < pc.host_items; ++l) f = host::xyzz_add(f, entry(seq, set, l));
+    return f;
+  };
   auto set_total = [&](size_t set) {
-    XYZZ F[5];
-    u32 L = pc.n_dev;   // F_0 .. F_L
-    for (u32 j = 0; j <= pc.n_dev; ++j) {
-      F[j] = entry(j, set, 0);
-      for (u32 l = 1; l < pc.host_items; ++l) F[j] = host::xyzz_add(F[j], entry(j, set, l));
-    }
+    if (pc.finished) return xyzz_to_host(hw + 64 * set);
+    const u32 nplanes = PLANES * (pc.n_dev + 1), w_seq = nplanes + 1;
+    XYZZ acc = host::xyzz_identity();
     if (pc.host_items > 1) {   // sum_l l W_l as the sum of the suffix sums from l = 1
-      XYZZ suffix = host::xyzz_identity(), v = host::xyzz_identity();
+      XYZZ suffix = host::xyzz_identity();
       for (u32 l = pc.host_items; l-- > 1;) {
-        suffix = host::xyzz_add(suffix, entry(pc.n_dev + 1, set, l));
-        v = host::xyzz_add(v, suffix);
+        suffix = host::xyzz_add(suffix, entry(w_seq, set, l));
+        acc = host::xyzz_add(acc, suffix);
       }
-      F[++L] = v;
     }
-    XYZZ acc = F[L];
-    for (u32 k = L; k-- > 0;) {
-      const u32 dbl = k == 0 ? 5 + pc.log_lb : 5;   // log2(GROUP) per level
-      for (u32 d = 0; d < dbl; ++d) acc = host::xyzz_double(acc);
-      acc = host::xyzz_add(acc, F[k]);
+    for (u32 b = nplanes; b-- > 0;) {
+      acc = host::xyzz_double(acc);
+      acc = host::xyzz_add(acc, seq_sum(1 + b, set));
     }
-    return acc;
+    for (u32 d = 0; d < pc.log_lb; ++d) acc = host::xyzz_double(acc);
+    return host::xyzz_add(acc, seq_sum(0, set));
   };
   for (u32 j = 0; j < pc.batch; ++j) {
     XYZZ total = host::xyzz_identity();

@@ -8,6 +8,9 @@ o = CpuOracle()
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = 1 << k
 ctx = pa.Context(0)
+for kv in os.environ.get("PM_OPTS", "").split(","):          # PM_OPTS=msm_reduce_wg=1,...
+    if kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 pts = o.g1_bases_arith(ints_to_limbs([0x1234567], 4)[0], ints_to_limbs([0xabcdef123456789abcdef], 4)[0], n, 16)
 sc = o.fr_sample(0x5343414C, n)
 d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
