@@ -73,7 +73,7 @@ def main():
                     help="skip the PCIe-inclusive and coset-4n NTT measurements (PMC passes: one NTT size only)")
     ap.add_argument("--prover-log-n", type=int, default=20,
                     help="gates of the synthetic circuit for the full-prove entry (BASELINE configs[3])")
-    ap.add_argument("--cpu-prover-log-n", type=int, default=18,
+    ap.add_argument("--cpu-prover-log-n", type=int, default=20,
                     help="gates of the CPU-baseline proof (2^18: ~8 s on 16 threads; 2^20, the GPU leg's size: ~35 s)")
     ap.add_argument("--fourstep-log-n", type=int, default=0,
                     help="N > 1 only, off by default: also time ONE 2^K transform split over the ranks "
@@ -172,15 +172,35 @@ def main():
     barrier()
     for _ in range(max(args.warmup, 1)):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    # The timed region: EXACTLY args.steps steps between two barrier + synchronize brackets -- measured `repeats` times,
+    # each with the host clock around the brackets AND with a hipEvent pair recorded on the launch stream right after the
+    # opening bracket / right before the closing one.  `value` is from the MEDIAN region by the device clock: the host
+    # clock also counts the closing bracket itself (ctx.sync + synchronize, ~0.3 ms here), which a 5 ms region of 20
+    # steps sees as 6 % and a 50 ms region of 200 steps as 0.6 % (the driver's 20-step run read 8.4e10
+    # where the kernels do 9.6e10).  Both clocks are in the line (`timing`).
+    repeats = 9
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repeats)]
+    host_dts = []
+    for r_ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        ev[r_][0].record()
+        for _ in range(args.steps):
+            step()
+        ev[r_][1].record()
+        barrier()
+        host_dts.append(time.perf_counter() - t0)
+    dev_dts = [a_.elapsed_time(b_) * 1e-3 for a_, b_ in ev]
+    dt = max_over_ranks(float(np.median(dev_dts)))
+    dt_host = max_over_ranks(float(np.median(host_dts)))
     assert torch.equal(d_c, d_a), "iNTT(NTT(a)) != a"            # round trip inside the bench
     butterflies_per_step = 2 * (n // 2) * k
     value = world * butterflies_per_step * args.steps / dt
+    timing = {"clock": "hipEvent pair on the launch stream around exactly `steps` steps, inside the barrier + synchronize brackets",
+              "repeats": repeats, "region_ms_device_median": round(dt * 1e3, 4),
+              "region_ms_device_min_max": [round(min(dev_dts) * 1e3, 4), round(max(dev_dts) * 1e3, 4)],
+              "region_ms_host_clock_median": round(dt_host * 1e3, 4),
+              "value_by_host_clock": world * butterflies_per_step * args.steps / dt_host}
     prof_steps = max(20, min(args.steps, 200))
     ctx.profile(True)
     barrier()
@@ -201,15 +221,31 @@ def main():
     s_dom = passes[0] if dom.endswith("first") or dom.endswith("single") else passes[-1]
     algo_bytes = 64 * n * s_dom / k                                # 64 N bytes per transform, S/k of it per pass
     achieved = algo_bytes / (dom_ms * 1e-3)
-    # `traffic` (HBM bytes from PMC counters) is only ever reported when measured in this run; the PMC passes
-    # are separate rocprofv3 runs (tools/collect_pmc.sh) whose summaries live under profiles/ as evidence
+    # `traffic` (HBM bytes per launch from the PMC counters, FETCH_SIZE x 2 + WRITE_SIZE: the gfx950 correction of
+    # MI355X_MICROARCH.md) cannot be collected inside this process: the PMC passes are separate rocprofv3 runs of THIS
+    # command (tools/collect_pmc.sh -> tools/pmc_summary.py).  When their summary for this round is in profiles/ and has
+    # the dominant kernel at this size, its figure is quoted (with its source); otherwise null.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_summary.json")
+    if os.path.exists(pmc_path):
+        # ntt_pass4_kernel<S, LT, OUT_UFAST, IN_WIDE, OUT_WIDE>: the first pass reads canonical and writes wide, the last the reverse
+        role_args = {"first": "false, true>", "last": "true, false>", "single": "false, false>", "middle": "true, true>"}
+        want = role_args[dom.rsplit("_", 1)[1]]
+        try:
+            with open(pmc_path) as f_:
+                for name_, ent_ in json.load(f_).items():
+                    if "ntt_pass" in name_ and want in name_ and f"grid={n // 4} " in name_ + " " \
+                            and "hbm_bytes_per_launch_corrected" in ent_:
+                        traffic, traffic_src = int(ent_["hbm_bytes_per_launch_corrected"]), f"profiles/r04_pmc_summary.json [{name_}]"
+        except (OSError, ValueError):
+            pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(dom_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(algo_bytes),
                 "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()},
                 "measured_in": f"a separate profiled loop of {prof_steps} steps ({dt_prof * 1e3:.4f} ms per step with an event "
                                f"pair around every kernel); `value` is from the loop with the timers off",
-                "pmc_evidence": "profiles/r03_pmc_summary.json (offline rocprofv3 --pmc passes of this command)",
+                "pmc_evidence": "profiles/r04_pmc_summary.json (offline rocprofv3 --pmc passes of this command)",
                 "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
 
     # ------------------------------------------------------------------ NTT extras (rank 0): SURVEY 8d
@@ -828,6 +864,7 @@ def main():
     if rank == 0:
         out = {"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": value, "unit": "butterflies/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "timing": timing,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, Fr)",
                "data": "synthetic",
                "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "

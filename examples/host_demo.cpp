@@ -51,6 +51,14 @@ int main() {
     REQUIRE(inplace == dom.fft(a));
     std::vector<Fr> el = dom.elements();
     REQUIRE(el[0] == EvaluationDomain::one() && el[1] == dom.group_gen);
+    // the small domain helpers: Z_H vanishes on H, the Lagrange basis at w^5 is the indicator of 5, and the vanishing
+    // polynomial of degree 256 on the coset takes four values over the 1024-point domain
+    const Fr zero_fr{0, 0, 0, 0};
+    REQUIRE(dom.evaluate_vanishing_polynomial(el[7]) == zero_fr && !(dom.evaluate_vanishing_polynomial(random_fr()) == zero_fr));
+    std::vector<Fr> lag = dom.evaluate_all_lagrange_coefficients(el[5]);
+    REQUIRE(lag[5] == EvaluationDomain::one() && lag[4] == zero_fr && lag[1023] == zero_fr);
+    std::vector<Fr> vh = dom.compute_vanishing_poly_over_coset(256);
+    REQUIRE(vh[0] == vh[4] && vh[1] == vh[1021] && !(vh[0] == vh[1]));
     auto many = dom.fft_many({a, b, a}, PM_NTT_COSET);
     REQUIRE(many.size() == 3 && many[0] == dom.coset_fft(a) && many[1] == dom.coset_fft(b) && many[2] == many[0]);
     bool threw = false;

@@ -102,6 +102,23 @@ int pm_trim(pm_ctx* ctx, size_t* freed_bytes);
 int pm_domain_info(uint32_t log_n, uint64_t group_gen[4], uint64_t group_gen_inv[4],
                    uint64_t size_inv[4]);
 
+/* EvaluationDomain's small helpers (dusk-plonk 0.8.2 fft::domain, ref:Cargo.toml:19) -- what a patch
+ * at the quotient_poly::compute / linearisation_poly level calls besides the transforms.  The plain forms are pure host
+ * arithmetic on host buffers and need no context; the _dev forms fill a device vector of 2^log_n canonical Fr (Montgomery
+ * limbs) with the library's kernels (pm_fr_powers_dev, pm_fr_vec_op_dev, pm_fr_batch_inverse_dev) and return when it is
+ * complete.  PM_ERR_DOMAIN_TOO_LARGE when log_n >= 32.
+ *   evaluate_vanishing_polynomial(tau)             = tau^size - 1
+ *   compute_vanishing_poly_over_coset(poly_degree)   out[i] = (g w^i)^poly_degree - 1, g = GENERATOR = 7, w = group_gen;
+ *                                                    upstream asserts size > poly_degree: PM_ERR_BAD_ARG otherwise
+ *   evaluate_all_lagrange_coefficients(tau)          out[i] = L_i(tau) = (tau^size - 1) / size * w^i / (tau - w^i);
+ *                                                    tau = w^j in the domain: the indicator vector of j */
+int pm_domain_evaluate_vanishing_polynomial(uint32_t log_n, const uint64_t tau[4], uint64_t out[4]);
+int pm_domain_vanishing_poly_over_coset(uint32_t log_n, uint64_t poly_degree, uint64_t* out);
+int pm_domain_vanishing_poly_over_coset_dev(pm_ctx* ctx, uint32_t log_n, uint64_t poly_degree, void* d_out, void* hip_stream);
+int pm_domain_evaluate_all_lagrange_coefficients(uint32_t log_n, const uint64_t tau[4], uint64_t* out);
+int pm_domain_evaluate_all_lagrange_coefficients_dev(pm_ctx* ctx, uint32_t log_n, const uint64_t tau[4], void* d_out,
+                                                     void* hip_stream);
+
 /* Build (and cache on the device) the twiddle tables of the 2^log_n domain.  Optional: the
  * first transform of a size does it implicitly. */
 int pm_domain_prepare(pm_ctx* ctx, uint32_t log_n);

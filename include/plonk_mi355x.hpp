@@ -101,6 +101,28 @@ class EvaluationDomain {
     x.back() = one();
     return fft(x);
   }
+  // evaluate_vanishing_polynomial(tau) = tau^size - 1
+  Fr evaluate_vanishing_polynomial(const Fr& tau) const {
+    Fr out{};
+    int rc = pm_domain_evaluate_vanishing_polynomial(log_size_of_group, tau.data(), out.data());
+    if (rc != PM_OK) throw Error(rc, "pm_domain_evaluate_vanishing_polynomial");
+    return out;
+  }
+  // evaluate_all_lagrange_coefficients(tau): [L_0(tau), .., L_(size-1)(tau)]
+  std::vector<Fr> evaluate_all_lagrange_coefficients(const Fr& tau) const {
+    std::vector<Fr> out(size);
+    int rc = pm_domain_evaluate_all_lagrange_coefficients(log_size_of_group, tau.data(), out[0].data());
+    if (rc != PM_OK) throw Error(rc, "pm_domain_evaluate_all_lagrange_coefficients");
+    return out;
+  }
+  // compute_vanishing_poly_over_coset(*this, poly_degree): X^poly_degree - 1 on GENERATOR * H, over this domain
+  // (upstream asserts size > poly_degree: Error{PM_ERR_BAD_ARG})
+  std::vector<Fr> compute_vanishing_poly_over_coset(uint64_t poly_degree) const {
+    std::vector<Fr> out(size);
+    int rc = pm_domain_vanishing_poly_over_coset(log_size_of_group, poly_degree, out[0].data());
+    if (rc != PM_OK) throw Error(rc, "compute_vanishing_poly_over_coset: domain size > poly_degree violated");
+    return out;
+  }
   static Fr one() { return Fr{0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL}; }
 
  private:

@@ -105,6 +105,27 @@ class Domain:
             yield w
             w = w * self.group_gen % R_MOD
 
+    # the small helpers of dusk_plonk::fft::domain (dusk-plonk 0.8.2, ref:Cargo.toml:19), from
+    # their definitions -- no batch inversion, no running products: one modular inverse per element
+    def evaluate_vanishing_polynomial(self, tau: int) -> int:
+        """Z_H(tau) = tau^size - 1."""
+        return (pow(tau, self.size, R_MOD) - 1) % R_MOD
+
+    def compute_vanishing_poly_over_coset(self, poly_degree: int) -> list[int]:
+        """[(g w^i)^poly_degree - 1 for i < size], g = GENERATOR; upstream asserts size > poly_degree."""
+        if not self.size > poly_degree:
+            raise ValueError("domain_size > poly_degree")
+        return [(pow(FR_GENERATOR * pow(self.group_gen, i, R_MOD) % R_MOD, poly_degree, R_MOD) - 1) % R_MOD
+                for i in range(self.size)]
+
+    def evaluate_all_lagrange_coefficients(self, tau: int) -> list[int]:
+        """[L_i(tau)]: L_i(X) = prod_{j != i} (X - w^j) / (w^i - w^j) = (X^n - 1) w^i / (n (X - w^i))."""
+        els = list(self.elements())
+        if tau % R_MOD in els:
+            return [1 if e == tau % R_MOD else 0 for e in els]
+        zh = self.evaluate_vanishing_polynomial(tau)
+        return [zh * e % R_MOD * pow(self.size * (tau - e) % R_MOD, -1, R_MOD) % R_MOD for e in els]
+
 
 def naive_dft(a: list[int], omega: int) -> list[int]:
     """O(n^2) definition: out[j] = sum_i a[i] * omega^(i j)."""

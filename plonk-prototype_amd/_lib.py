@@ -55,6 +55,11 @@ SIGNATURES = {
     "pm_trim": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "pm_domain_info": (C.c_int, [C.c_uint32, u64p, u64p, u64p]),
     "pm_domain_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pm_domain_evaluate_vanishing_polynomial": (C.c_int, [C.c_uint32, u64p, u64p]),
+    "pm_domain_vanishing_poly_over_coset": (C.c_int, [C.c_uint32, C.c_uint64, u64p]),
+    "pm_domain_vanishing_poly_over_coset_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pm_domain_evaluate_all_lagrange_coefficients": (C.c_int, [C.c_uint32, u64p, u64p]),
+    "pm_domain_evaluate_all_lagrange_coefficients_dev": (C.c_int, [C.c_void_p, C.c_uint32, u64p, C.c_void_p, C.c_void_p]),
     "pm_fr_ntt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_uint32, C.c_uint32]),
     "pm_fr_ntt_batch": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, C.c_size_t,
                                   C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -414,6 +414,161 @@ extern "C" int pm_domain_info(uint32_t log_n, uint64_t group_gen[4], uint64_t gr
   return PM_OK;
 }
 
+// ---- the small helpers of dusk_plonk::fft::EvaluationDomain (dusk-plonk 0.8.2, ref:Cargo.toml:19):
+// what a Rust patch at the quotient_poly::compute / linearisation level calls besides the transforms.
+namespace {
+HFr hfr_pow_u64(const HFr& a, host::u64 e) { return host::pow(a, &e, 1, host::FR()); }
+// log of tau to the base w (a generator of the 2^log_n domain), or -1 when tau is not in the domain: Pohlig-Hellman
+// over the 2-group, one bit per step
+long long domain_log(const HFr& tau, unsigned log_n) {
+  const host::Field<4>& F = host::FR();
+  const HFr one = host::one(F), w = domain_gen(log_n), wi = host::inv(w, F);
+  u64 idx = 0;
+  HFr rest = tau;   // tau w^-idx: its order divides 2^(log_n - j) after step j
+  HFr wpow = wi;    // w^-(2^j)
+  for (unsigned j = 0; j < log_n; ++j) {
+    HFr t = rest;
+    for (unsigned s = 0; s + j + 1 < log_n; ++s) t = host::mul(t, t, F);   // rest^(2^(log_n - 1 - j)): 1 or -1
+    if (!host::eq(t, one)) {
+      idx |= (u64)1 << j;
+      rest = host::mul(rest, wpow, F);
+    }
+    wpow = host::mul(wpow, wpow, F);
+  }
+  return host::eq(rest, one) ? (long long)idx : -1;
+}
+}  // namespace
+
+// EvaluationDomain::evaluate_vanishing_polynomial(tau) = tau^size - 1
+extern "C" int pm_domain_evaluate_vanishing_polynomial(uint32_t log_n, const uint64_t tau[4], uint64_t out[4]) {
+  if (!tau || !out) return PM_ERR_BAD_ARG;
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  const host::Field<4>& F = host::FR();
+  HFr t;
+  memcpy(t.l, tau, 32);
+  const HFr r = host::sub(hfr_pow_u64(t, (u64)1 << log_n), host::one(F), F);
+  memcpy(out, r.l, 32);
+  return PM_OK;
+}
+
+// fft::domain::compute_vanishing_poly_over_coset(domain, poly_degree): Evaluations over the 2^log_n domain of
+// X^poly_degree - 1 on the coset g H:  out[i] = g^d (w^d)^i - 1,  g = GENERATOR = 7.  Upstream asserts size > poly_degree.
+extern "C" int pm_domain_vanishing_poly_over_coset(uint32_t log_n, uint64_t poly_degree, uint64_t* out) {
+  if (!out) return PM_ERR_BAD_ARG;
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  if (poly_degree >= ((u64)1 << log_n)) return PM_ERR_BAD_ARG;
+  const host::Field<4>& F = host::FR();
+  const HFr one = host::one(F), step = hfr_pow_u64(domain_gen(log_n), poly_degree);
+  HFr cur = hfr_pow_u64(host::from_u64(host::FR_GENERATOR, F), poly_degree);
+  for (size_t i = 0; i < ((size_t)1 << log_n); ++i) {
+    const HFr v = host::sub(cur, one, F);
+    memcpy(out + 4 * i, v.l, 32);
+    cur = host::mul(cur, step, F);
+  }
+  return PM_OK;
+}
+extern "C" int pm_domain_vanishing_poly_over_coset_dev(pm_ctx* ctx, uint32_t log_n, uint64_t poly_degree, void* d_out,
+                                                       void* hip_stream) {
+  if (!ctx || !d_out) return PM_ERR_BAD_ARG;
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  if (poly_degree >= ((u64)1 << log_n)) return PM_ERR_BAD_ARG;
+  const host::Field<4>& F = host::FR();
+  const HFr one = host::one(F), step = hfr_pow_u64(domain_gen(log_n), poly_degree);
+  const HFr scale = hfr_pow_u64(host::from_u64(host::FR_GENERATOR, F), poly_degree);
+  const size_t n = (size_t)1 << log_n;
+  int rc = pm_fr_powers_dev(ctx, step.l, scale.l, n, d_out, hip_stream);
+  // the scalar operand of the broadcast subtraction lives in the first element's place for one launch: a one-element
+  // device vector of its own, freed after the stream has used it
+  void* d_one = nullptr;
+  if (!rc) rc = pm_dev_alloc(ctx, 32, &d_one);
+  if (!rc) rc = pm_dev_upload(ctx, d_one, one.l, 32);
+  if (!rc) rc = pm_fr_vec_op_dev(ctx, 1 /* sub */, d_out, d_one, 1, d_out, n, hip_stream);
+  if (d_one) {
+    if (hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : ctx->stream) != hipSuccess && !rc) rc = PM_ERR_HIP;
+    (void)pm_dev_free(ctx, d_one);
+  }
+  return rc;
+}
+
+// EvaluationDomain::evaluate_all_lagrange_coefficients(tau): out[i] = L_i(tau) = (tau^n - 1) / n * w^i / (tau - w^i);
+// for tau = w^j in the domain the indicator of j.
+extern "C" int pm_domain_evaluate_all_lagrange_coefficients(uint32_t log_n, const uint64_t tau[4], uint64_t* out) {
+  if (!tau || !out) return PM_ERR_BAD_ARG;
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  const host::Field<4>& F = host::FR();
+  const size_t n = (size_t)1 << log_n;
+  HFr t;
+  memcpy(t.l, tau, 32);
+  const HFr one = host::one(F), w = domain_gen(log_n), tn = hfr_pow_u64(t, (u64)n);
+  if (host::eq(tn, one)) {
+    memset(out, 0, n * 32);
+    const long long j = domain_log(t, log_n);
+    if (j >= 0) memcpy(out + 4 * (size_t)j, one.l, 32);
+    return PM_OK;
+  }
+  // util::batch_inversion (Montgomery's trick) on u[i] = tau - w^i; the running products go to `out`
+  std::vector<HFr> u(n);
+  HFr r = one, acc = one;
+  for (size_t i = 0; i < n; ++i) {
+    u[i] = host::sub(t, r, F);
+    memcpy(out + 4 * i, acc.l, 32);          // product of u[0 .. i)
+    acc = host::mul(acc, u[i], F);
+    r = host::mul(r, w, F);
+  }
+  HFr inv_all = host::inv(acc, F);
+  const HFr l0 = host::mul(host::sub(tn, one, F), host::inv(host::from_u64((u64)n, F), F), F);   // (tau^n - 1) / n
+  const HFr wi = host::inv(w, F);
+  HFr l = host::mul(l0, hfr_pow_u64(w, (u64)(n - 1)), F);   // l0 w^(n-1), walked downwards
+  for (size_t i = n; i-- > 0;) {
+    HFr prefix;
+    memcpy(prefix.l, out + 4 * i, 32);
+    const HFr ui_inv = host::mul(inv_all, prefix, F);
+    inv_all = host::mul(inv_all, u[i], F);
+    const HFr v = host::mul(l, ui_inv, F);
+    memcpy(out + 4 * i, v.l, 32);
+    l = host::mul(l, wi, F);
+  }
+  return PM_OK;
+}
+extern "C" int pm_domain_evaluate_all_lagrange_coefficients_dev(pm_ctx* ctx, uint32_t log_n, const uint64_t tau[4], void* d_out,
+                                                                void* hip_stream) {
+  if (!ctx || !tau || !d_out) return PM_ERR_BAD_ARG;
+  if (log_n >= host::FR_TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+  const host::Field<4>& F = host::FR();
+  const size_t n = (size_t)1 << log_n;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  HFr t;
+  memcpy(t.l, tau, 32);
+  const HFr one = host::one(F), w = domain_gen(log_n), tn = hfr_pow_u64(t, (u64)n);
+  if (host::eq(tn, one)) {
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipMemsetAsync(d_out, 0, n * 32, st));
+    const long long j = domain_log(t, log_n);
+    if (j >= 0) {
+      PM_HIP(ctx, hipMemcpyAsync((char*)d_out + 32 * (size_t)j, one.l, 32, hipMemcpyHostToDevice, st));
+      PM_HIP(ctx, hipStreamSynchronize(st));   // `one` is a stack value
+    }
+    return PM_OK;
+  }
+  // out = w^i;  out -= tau  (= -(tau - w^i));  out = 1 / out;  out *= w^i scaled by -(tau^n - 1) / n
+  void *d_sc = nullptr, *d_roots = nullptr;
+  int rc = pm_dev_alloc(ctx, 32, &d_sc);
+  if (!rc) rc = pm_dev_alloc(ctx, n * 32, &d_roots);
+  const HFr neg_l0 = host::mul(host::sub(one, tn, F), host::inv(host::from_u64((u64)n, F), F), F);
+  if (!rc) rc = pm_fr_powers_dev(ctx, w.l, neg_l0.l, n, d_roots, hip_stream);   // -(tau^n - 1) / n * w^i
+  if (!rc) rc = pm_fr_powers_dev(ctx, w.l, one.l, n, d_out, hip_stream);
+  if (!rc) rc = pm_dev_upload(ctx, d_sc, t.l, 32);
+  if (!rc) rc = pm_fr_vec_op_dev(ctx, 1 /* sub */, d_out, d_sc, 1, d_out, n, hip_stream);
+  if (!rc) rc = pm_fr_batch_inverse_dev(ctx, d_out, n, hip_stream);
+  if (!rc) rc = pm_fr_vec_op_dev(ctx, 2 /* mul */, d_out, d_roots, n, d_out, n, hip_stream);
+  if (d_sc || d_roots) {
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = PM_ERR_HIP;
+    if (d_sc) (void)pm_dev_free(ctx, d_sc);
+    if (d_roots) (void)pm_dev_free(ctx, d_roots);
+  }
+  return rc;
+}
+
 // test hook (pure host): the pass plan ntt_run() follows for this size and these tunables (0 = the defaults of a fresh
 // context).  out[20]: passes, then per pass (up to 4) {log2 radix S, log2 columns per tile LT, threads per workgroup,
 // LDS bytes}, then a bit mask of the passes that have a kernel, then the blocked layout's log2 group size, 0.

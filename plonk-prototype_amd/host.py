@@ -413,6 +413,44 @@ class EvaluationDomain:
     def coset_ifft(self, evals):
         return self._run(evals, _lib.NTT_INVERSE | _lib.NTT_COSET)
 
+    def evaluate_vanishing_polynomial(self, tau) -> np.ndarray:
+        """``EvaluationDomain::evaluate_vanishing_polynomial``: tau^size - 1 (host arithmetic)."""
+        t, out = np.ascontiguousarray(tau, dtype=np.uint64).reshape(4), np.zeros(4, np.uint64)
+        rc = _lib.load().pm_domain_evaluate_vanishing_polynomial(self.log_size_of_group, _p(t), _p(out))
+        if rc != _lib.PM_OK:
+            raise Error(rc, "pm_domain_evaluate_vanishing_polynomial")
+        return out
+
+    def evaluate_all_lagrange_coefficients(self, tau, device: bool = False):
+        """``EvaluationDomain::evaluate_all_lagrange_coefficients``: [L_0(tau), .., L_(size-1)(tau)] -- on the host
+        ([size, 4] limbs), or with ``device=True`` as a :class:`DeviceVector` filled by the library's kernels."""
+        t = np.ascontiguousarray(tau, dtype=np.uint64).reshape(4)
+        if device:
+            v = DeviceVector(self.ctx, self.size)
+            self.ctx._check(self.ctx._lib.pm_domain_evaluate_all_lagrange_coefficients_dev(
+                self.ctx._h, self.log_size_of_group, _p(t), v._p, None))
+            return v
+        out = np.zeros((self.size, 4), np.uint64)
+        rc = _lib.load().pm_domain_evaluate_all_lagrange_coefficients(self.log_size_of_group, _p(t), _p(out))
+        if rc != _lib.PM_OK:
+            raise Error(rc, "pm_domain_evaluate_all_lagrange_coefficients")
+        return out
+
+    def compute_vanishing_poly_over_coset(self, poly_degree: int, device: bool = False):
+        """``fft::domain::compute_vanishing_poly_over_coset(domain, poly_degree)``: the evaluations over this
+        domain of X^poly_degree - 1 on the coset GENERATOR * H (in the prover: this = the 4n domain, poly_degree = n).
+        Upstream asserts ``size > poly_degree`` (here: PM_ERR_BAD_ARG)."""
+        if device:
+            v = DeviceVector(self.ctx, self.size)
+            self.ctx._check(self.ctx._lib.pm_domain_vanishing_poly_over_coset_dev(
+                self.ctx._h, self.log_size_of_group, poly_degree, v._p, None))
+            return v
+        out = np.zeros((self.size, 4), np.uint64)
+        rc = _lib.load().pm_domain_vanishing_poly_over_coset(self.log_size_of_group, poly_degree, _p(out))
+        if rc != _lib.PM_OK:
+            raise Error(rc, "size > poly_degree violated" if rc == _lib.PM_ERR_BAD_ARG else "log_size_of_group >= 32")
+        return out
+
     def elements(self):
         """All domain elements 1, g, g^2, ... = fft of X (the polynomial with coefficients [0, 1])."""
         if self.size == 1:
