@@ -373,6 +373,11 @@ int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, 
                    pm_plonk_proof* out);
 /* Proof::to_bytes: 11 x 48-byte compressed G1, then the 16 scalars of ProofEvaluations::to_bytes. */
 int pm_plonk_proof_to_bytes(const pm_plonk_proof* proof, uint8_t out[PM_PLONK_PROOF_BYTES]);
+/* Every label string of the transcript, in message order, as "key=label" lines (a static string).  The labels are
+ * restated from the published dusk-plonk 0.8 design and are PARITY-UNPINNED; they live in ONE table (csrc/prover.hip,
+ * namespace tl) that both the native prover and the Python verifier side read -- the single place to edit when
+ * upstream vectors become available. */
+const char* pm_plonk_transcript_labels(void);
 /* The same with the SRS split over the GPUs of a node (BASELINE.json configs[4]): every rank calls this with
  * the same witness and its own slice of the commit key -- bases for coefficients [first_coefficient,
  * first_coefficient + pm_g1_bases_len(slice)) -- and `exchange` turns this rank's k partial points (k x 18

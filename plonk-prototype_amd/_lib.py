@@ -109,6 +109,7 @@ SIGNATURES = {
                                  C.POINTER(PlonkProof)]),
     "pm_plonk_prove_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, u64p, u64p,
                                          C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(PlonkProof)]),
+    "pm_plonk_transcript_labels": (C.c_char_p, []),
     "pm_plonk_proof_to_bytes": (C.c_int, [C.POINTER(PlonkProof), C.POINTER(C.c_uint8)]),
     "pm_fr_poly_evaluate_many_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_size_t, u64p, u64p,
                                                C.c_void_p]),

@@ -167,10 +167,56 @@ char* at(void* base, size_t elems) { return (char*)base + 32 * elems; }
 
 // selector order of dusk's VerifierKey::seed_transcript (and of the ABI)
 enum { Q_M, Q_L, Q_R, Q_O, Q_C, Q_4, Q_ARITH, Q_RANGE, Q_LOGIC, Q_FIXED, Q_VAR, NSEL };
-const char* SEL_LABELS[NSEL] = {"q_m", "q_l", "q_r", "q_o", "q_c", "q_4", "q_arith", "q_range", "q_logic",
-                                "q_variable_group_add", "q_fixed_group_add"};   // (transcript order: variable before fixed)
 const int SEL_SEED_ORDER[NSEL] = {Q_M, Q_L, Q_R, Q_O, Q_C, Q_4, Q_ARITH, Q_RANGE, Q_LOGIC, Q_VAR, Q_FIXED};
-const char* SIGMA_LABELS[4] = {"left_sigma", "right_sigma", "out_sigma", "fourth_sigma"};
+
+// ================================================================================================================
+// THE transcript table: every label string and the order of every message of a proof's Fiat-Shamir transcript, in
+// the order they are absorbed / squeezed.  Restated from the published dusk-plonk 0.8 design (ref:Cargo.toml:19); the
+// crate is not in the reference tree and no upstream proof bytes exist here, so these strings are PARITY-UNPINNED:
+// byte-equality of a proof with dusk's stands or falls with them.  THIS IS THE SINGLE PLACE TO EDIT when upstream
+// vectors become available -- the prover below only refers to this table, and the verifier side in Python
+// (plonk-prototype_amd/prover.py: derive_challenges) reads the same table through pm_plonk_transcript_labels().
+// ================================================================================================================
+namespace tl {
+const char* const PROTOCOL = "plonk";                       // default Transcript::new(label)
+// VerifierKey::seed_transcript: the 11 selector commitments in SEL_SEED_ORDER (variable before fixed), the 4 sigmas
+const char* const SELECTORS[NSEL] = {"q_m", "q_l", "q_r", "q_o", "q_c", "q_4", "q_arith", "q_range", "q_logic",
+                                     "q_variable_group_add", "q_fixed_group_add"};
+const char* const SIGMAS[4] = {"left_sigma", "right_sigma", "out_sigma", "fourth_sigma"};
+// circuit_domain_sep(n)
+const char* const DOM_SEP = "dom-sep";
+const char* const DOM_SEP_VALUE = "circuit_size";
+const char* const CIRCUIT_SIZE = "n";
+// this library's public-input binding (flags = 0; absent with PM_PLONK_UPSTREAM_TRANSCRIPT): count, then (position, value)
+const char* const PI_LEN = "pi_len";
+const char* const PI_POS = "pi_pos";
+const char* const PI_VALUE = "pi";
+// round 1: the wire commitments
+const char* const WIRES[4] = {"w_l", "w_r", "w_o", "w_4"};
+// round 2: beta (re-absorbed under its own label), gamma, then the permutation commitment
+const char* const BETA = "beta";
+const char* const GAMMA = "gamma";
+const char* const PERM = "z";
+// round 3: the quotient's challenges, then the four quotient commitments
+const char* const ALPHA = "alpha";
+const char* const RANGE_SEP = "range separation challenge";
+const char* const LOGIC_SEP = "logic separation challenge";
+const char* const FIXED_SEP = "fixed base separation challenge";
+const char* const VAR_SEP = "variable base separation challenge";
+const char* const QUOTIENT[4] = {"t_1", "t_2", "t_3", "t_4"};
+// round 4: the evaluation challenge and the 17 evaluations in transcript order (pm_plonk_proof.evaluations)
+const char* const Z_CHALLENGE = "z";
+const char* const EVALS[17] = {"a_eval", "b_eval", "c_eval", "d_eval", "a_next_eval", "b_next_eval", "d_next_eval",
+                               "left_sig_eval", "right_sig_eval", "out_sig_eval", "q_arith_eval", "q_c_eval", "q_l_eval",
+                               "q_r_eval", "perm_eval", "t_eval", "r_eval"};
+// round 5: the two aggregation challenges (same label twice), then the opening commitments; the verifier's batch challenge
+const char* const AGGREGATE = "aggregate_witness";
+const char* const W_Z = "w_z";
+const char* const W_ZW = "w_z_w";
+const char* const BATCH = "batch";
+}  // namespace tl
+const char* const* const SEL_LABELS = tl::SELECTORS;
+const char* const* const SIGMA_LABELS = tl::SIGMAS;
 
 // ---- the widgets' linearisation scalars: the same identities as plonk_rounds.hip's quotient kernel,
 // on the opening evaluations (widget::*::ProverKey::compute_linearisation)
@@ -245,7 +291,7 @@ struct pm_prover_key {
   // verifier key (commitments to the 11 selector and 4 sigma polynomials) and the transcript seeded with it
   bool committed = false;
   u64 vk[NSEL + 4][12] = {};
-  Transcript base{std::string("plonk")};
+  Transcript base{std::string("plonk")};   // overwritten by key_commit (tl::PROTOCOL or the caller's label)
   std::atomic<bool> busy{false};       // a proof is running on this key's workspace
   hipStream_t side = nullptr;         // second stream: work that does not depend on the next challenge
   hipEvent_t ev_main = nullptr, ev_side = nullptr;
@@ -546,15 +592,51 @@ static int key_commit_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, c
   PK_TRY(commit_batch(ctx, ck, shard, pk->sel_coeffs, n, n, NSEL, &pk->vk[0]));
   PK_TRY(commit_batch(ctx, ck, shard, pk->sigma_coeffs, n, n, 4, &pk->vk[NSEL]));
   // Prover::preprocess: Transcript::new(label), VerifierKey::seed_transcript, circuit_domain_sep(n)
-  Transcript ts(transcript_label ? transcript_label : "plonk");
+  Transcript ts(transcript_label ? transcript_label : tl::PROTOCOL);
   for (int i = 0; i < NSEL; ++i) ts.append_commitment(SEL_LABELS[i], pk->vk[SEL_SEED_ORDER[i]]);
   for (int j = 0; j < 4; ++j) ts.append_commitment(SIGMA_LABELS[j], pk->vk[NSEL + j]);
-  ts.append("dom-sep", (const uint8_t*)"circuit_size", 12);
-  ts.append_u64("n", n);
+  ts.append(tl::DOM_SEP, (const uint8_t*)tl::DOM_SEP_VALUE, strlen(tl::DOM_SEP_VALUE));
+  ts.append_u64(tl::CIRCUIT_SIZE, n);
   pk->base = ts;
   pk->committed = true;
   if (vk_out) memcpy(vk_out, pk->vk, sizeof pk->vk);
   return PM_OK;
+}
+
+// The table above as text, one "key=label" line per entry in transcript order (the verifier side in Python reads it:
+// one table for both sides).
+extern "C" const char* pm_plonk_transcript_labels(void) {
+  static const std::string text = [] {
+    std::string t;
+    auto add = [&](const std::string& k, const char* v) { t += k + "=" + v + "\n"; };
+    add("protocol", tl::PROTOCOL);
+    for (int i = 0; i < NSEL; ++i) add("selector_" + std::to_string(i), tl::SELECTORS[i]);
+    for (int i = 0; i < 4; ++i) add("sigma_" + std::to_string(i), tl::SIGMAS[i]);
+    add("dom_sep", tl::DOM_SEP);
+    add("dom_sep_value", tl::DOM_SEP_VALUE);
+    add("circuit_size", tl::CIRCUIT_SIZE);
+    add("pi_len", tl::PI_LEN);
+    add("pi_pos", tl::PI_POS);
+    add("pi_value", tl::PI_VALUE);
+    for (int i = 0; i < 4; ++i) add("wire_" + std::to_string(i), tl::WIRES[i]);
+    add("beta", tl::BETA);
+    add("gamma", tl::GAMMA);
+    add("perm", tl::PERM);
+    add("alpha", tl::ALPHA);
+    add("range_sep", tl::RANGE_SEP);
+    add("logic_sep", tl::LOGIC_SEP);
+    add("fixed_sep", tl::FIXED_SEP);
+    add("var_sep", tl::VAR_SEP);
+    for (int i = 0; i < 4; ++i) add("quotient_" + std::to_string(i), tl::QUOTIENT[i]);
+    add("z_challenge", tl::Z_CHALLENGE);
+    for (int i = 0; i < 17; ++i) add("eval_" + std::to_string(i), tl::EVALS[i]);
+    add("aggregate", tl::AGGREGATE);
+    add("w_z", tl::W_Z);
+    add("w_zw", tl::W_ZW);
+    add("batch", tl::BATCH);
+    return t;
+  }();
+  return text.c_str();
 }
 
 extern "C" int pm_plonk_key_commit(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, const char* transcript_label,
@@ -671,10 +753,10 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   if (!(flags & PM_PLONK_UPSTREAM_TRANSCRIPT)) {
     // the default; not in dusk-plonk 0.8.2 (its transcript never sees the public inputs): binds the statement to
     // the challenges so that it cannot be chosen after them
-    ts.append_u64("pi_len", n_pi);
+    ts.append_u64(tl::PI_LEN, n_pi);
     for (size_t i = 0; i < n_pi; ++i) {
-      ts.append_u64("pi_pos", pi_positions[i]);
-      ts.append_scalar("pi", get(pi_values + 4 * i));
+      ts.append_u64(tl::PI_POS, pi_positions[i]);
+      ts.append_scalar(tl::PI_VALUE, get(pi_values + 4 * i));
     }
   }
   const HFr one = fone();
@@ -692,12 +774,11 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     PK_TRY(pm_fr_ntt_dev(ctx, pi_coeffs, n, n, at(pk->coset, 4 * n * 5), 4 * n, lg + 2, 1, PM_NTT_COSET, side));
   }
   PK_TRY(commit_batch(ctx, ck, shard, pk->coeffs, n, n, 4, &out->commitments[0]));
-  const char* wl[4] = {"w_l", "w_r", "w_o", "w_4"};
-  for (int j = 0; j < 4; ++j) ts.append_commitment(wl[j], out->commitments[j]);
+  for (int j = 0; j < 4; ++j) ts.append_commitment(tl::WIRES[j], out->commitments[j]);
   // ---- round 2 --------------------------------------------------------------------------------
-  const HFr beta = ts.challenge_scalar("beta");
-  ts.append_scalar("beta", beta);
-  const HFr gamma = ts.challenge_scalar("gamma");
+  const HFr beta = ts.challenge_scalar(tl::BETA);
+  ts.append_scalar(tl::BETA, beta);
+  const HFr gamma = ts.challenge_scalar(tl::GAMMA);
   pm_plonk_perm_args pa;
   memset(&pa, 0, sizeof pa);
   for (int j = 0; j < 4; ++j) {
@@ -718,13 +799,13 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   PK_TRY(pm_stream_fork(ctx, side, pk->ev_main));
   PK_TRY(pm_fr_ntt_dev(ctx, z_coeffs, n, n, at(pk->coset, 4 * n * 4), 4 * n, lg + 2, 1, PM_NTT_COSET, side));
   PK_TRY(commit_batch(ctx, ck, shard, z_coeffs, n, n, 1, &out->commitments[4]));
-  ts.append_commitment("z", out->commitments[4]);
+  ts.append_commitment(tl::PERM, out->commitments[4]);
   // ---- round 3 --------------------------------------------------------------------------------
-  const HFr alpha = ts.challenge_scalar("alpha");
-  const HFr range_sep = ts.challenge_scalar("range separation challenge");
-  const HFr logic_sep = ts.challenge_scalar("logic separation challenge");
-  const HFr fixed_sep = ts.challenge_scalar("fixed base separation challenge");
-  const HFr var_sep = ts.challenge_scalar("variable base separation challenge");
+  const HFr alpha = ts.challenge_scalar(tl::ALPHA);
+  const HFr range_sep = ts.challenge_scalar(tl::RANGE_SEP);
+  const HFr logic_sep = ts.challenge_scalar(tl::LOGIC_SEP);
+  const HFr fixed_sep = ts.challenge_scalar(tl::FIXED_SEP);
+  const HFr var_sep = ts.challenge_scalar(tl::VAR_SEP);
   PK_TRY(pm_stream_join(ctx, side, pk->ev_side));   // the wire, PI and z coset forms are ready
   pm_plonk_quotient_args qa;
   memset(&qa, 0, sizeof qa);
@@ -759,10 +840,9 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   PK_TRY(pm_plonk_quotient_dev(ctx, &qa, n, pk->t, nullptr));
   PK_TRY(pm_fr_ntt_dev(ctx, pk->t, 4 * n, 4 * n, pk->t, 4 * n, lg + 2, 1, PM_NTT_INVERSE | PM_NTT_COSET, nullptr));
   PK_TRY(commit_batch(ctx, ck, shard, pk->t, n, n, 4, &out->commitments[5]));
-  const char* tl[4] = {"t_1", "t_2", "t_3", "t_4"};
-  for (int i = 0; i < 4; ++i) ts.append_commitment(tl[i], out->commitments[5 + i]);
+  for (int i = 0; i < 4; ++i) ts.append_commitment(tl::QUOTIENT[i], out->commitments[5 + i]);
   // ---- round 4 --------------------------------------------------------------------------------
-  const HFr zc = ts.challenge_scalar("z"), zw = fmul(zc, pk->omega);
+  const HFr zc = ts.challenge_scalar(tl::Z_CHALLENGE), zw = fmul(zc, pk->omega);
   enum { E_A, E_B, E_C, E_D, E_AN, E_BN, E_DN, E_S1, E_S2, E_S3, E_QARITH, E_QC, E_QL, E_QR, E_ZN, E_T, E_R, NEV };
   HFr ev[NEV];
   {
@@ -829,15 +909,13 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     PK_TRY(pm_fr_lincomb_dev(ctx, k, lin_v, &lin_c[0][0], n, pk->r, nullptr));
   }
   PK_TRY(pm_fr_poly_evaluate_dev(ctx, pk->r, n, zc.l, ev[E_R].l, nullptr));
-  const char* el[NEV] = {"a_eval", "b_eval", "c_eval", "d_eval", "a_next_eval", "b_next_eval", "d_next_eval",
-                         "left_sig_eval", "right_sig_eval", "out_sig_eval", "q_arith_eval", "q_c_eval", "q_l_eval",
-                         "q_r_eval", "perm_eval", "t_eval", "r_eval"};
+  static_assert(NEV == 17, "tl::EVALS lists the evaluations in this enum's order");
   for (int i = 0; i < NEV; ++i) {
-    ts.append_scalar(el[i], ev[i]);
+    ts.append_scalar(tl::EVALS[i], ev[i]);
     put(out->evaluations[i], ev[i]);
   }
   // ---- round 5: CommitKey::compute_aggregate_witness at z and at z w ------------------------------
-  const HFr aw = ts.challenge_scalar("aggregate_witness");
+  const HFr aw = ts.challenge_scalar(tl::AGGREGATE);
   {
     const void* agg_v[12];
     u64 agg_c[12][4];
@@ -859,7 +937,7 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     PK_TRY(pm_fr_lincomb_dev(ctx, 12, agg_v, &agg_c[0][0], n, pk->agg, nullptr));
     PK_TRY(pm_fr_poly_ruffini_dev(ctx, pk->agg, n, zc.l, pk->wit, nullptr));
   }
-  const HFr aws = ts.challenge_scalar("aggregate_witness");
+  const HFr aws = ts.challenge_scalar(tl::AGGREGATE);
   {
     const void* sh_v[4] = {z_coeffs, at(pk->coeffs, 0), at(pk->coeffs, n), at(pk->coeffs, 3 * n)};
     u64 sh_c[4][4];
@@ -872,8 +950,8 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     PK_TRY(pm_fr_poly_ruffini_dev(ctx, pk->agg, n, zw.l, at(pk->wit, n), nullptr));
   }
   PK_TRY(commit_batch(ctx, ck, shard, pk->wit, n - 1, n, 2, &out->commitments[9]));
-  ts.append_commitment("w_z", out->commitments[9]);
-  ts.append_commitment("w_z_w", out->commitments[10]);
+  ts.append_commitment(tl::W_Z, out->commitments[9]);
+  ts.append_commitment(tl::W_ZW, out->commitments[10]);
   const HFr chal[10] = {beta, gamma, alpha, range_sep, logic_sep, fixed_sep, var_sep, zc, aw, aws};
   for (int i = 0; i < 10; ++i) put(out->challenges[i], chal[i]);
   return PM_OK;

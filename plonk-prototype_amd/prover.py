@@ -36,13 +36,21 @@ SELECTORS = ("q_m", "q_l", "q_r", "q_o", "q_c", "q_4", "q_arith", "q_range", "q_
 # VerifierKey::seed_transcript order
 _SEED_ORDER = ("q_m", "q_l", "q_r", "q_o", "q_c", "q_4", "q_arith", "q_range", "q_logic", "q_variable_group_add",
                "q_fixed_group_add")
-_SIGMA_LABELS = (b"left_sigma", b"right_sigma", b"out_sigma", b"fourth_sigma")
 VK_NAMES = SELECTORS + ("sigma_1", "sigma_2", "sigma_3", "sigma_4")
 CHALLENGES = ("beta", "gamma", "alpha", "range_sep", "logic_sep", "fixed_sep", "var_sep", "z", "aw", "aw_shifted")
-_EVAL_LABELS = {"a": b"a_eval", "b": b"b_eval", "c": b"c_eval", "d": b"d_eval", "a_next": b"a_next_eval",
-                "b_next": b"b_next_eval", "d_next": b"d_next_eval", "sigma_1": b"left_sig_eval",
-                "sigma_2": b"right_sig_eval", "sigma_3": b"out_sig_eval", "q_arith": b"q_arith_eval", "q_c": b"q_c_eval",
-                "q_l": b"q_l_eval", "q_r": b"q_r_eval", "z_next": b"perm_eval", "t": b"t_eval", "r": b"r_eval"}
+
+_labels_cache: dict | None = None
+
+
+def transcript_labels() -> dict:
+    """Every label string of the transcript, from the ONE table both sides use (csrc/prover.hip, namespace tl, through
+    ``pm_plonk_transcript_labels``): {key: bytes}.  The labels are restated from the published dusk-plonk 0.8 design --
+    parity-unpinned -- and that table is the single place to edit when upstream vectors become available."""
+    global _labels_cache
+    if _labels_cache is None:
+        text = _lib.load().pm_plonk_transcript_labels().decode()
+        _labels_cache = {k: v.encode() for k, v in (line.split("=", 1) for line in text.splitlines() if line)}
+    return _labels_cache
 
 
 @dataclass
@@ -254,51 +262,55 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, bind_public
     return proof
 
 
-def seeded_transcript(verifier_key: dict, n: int, label: bytes = b"plonk") -> Transcript:
+def seeded_transcript(verifier_key: dict, n: int, label: bytes | None = None) -> Transcript:
     """``Prover::preprocess`` / ``Verifier::preprocess``: the transcript after ``VerifierKey::seed_transcript``."""
-    ts = Transcript(label)
-    for nm in _SEED_ORDER:
-        ts.append_commitment(nm.encode(), verifier_key[nm])
-    for j, lab in enumerate(_SIGMA_LABELS):
-        ts.append_commitment(lab, verifier_key[f"sigma_{j + 1}"])
-    ts.circuit_domain_sep(n)
+    L = transcript_labels()
+    ts = Transcript(label if label is not None else L["protocol"])
+    for i, nm in enumerate(_SEED_ORDER):
+        ts.append_commitment(L[f"selector_{i}"], verifier_key[nm])
+    for j in range(4):
+        ts.append_commitment(L[f"sigma_{j}"], verifier_key[f"sigma_{j + 1}"])
+    ts.append_message(L["dom_sep"], L["dom_sep_value"])
+    ts.append_u64(L["circuit_size"], n)
     return ts
 
 
 def derive_challenges(proof: Proof, verifier_key: dict, n: int, public_inputs=None, bind_public_inputs: bool = True,
-                      label: bytes = b"plonk", t_eval=None) -> dict:
+                      label: bytes | None = None, t_eval=None) -> dict:
     """The verifier's side of Fiat-Shamir: replay the transcript over the verifier key, the public inputs
     and the proof's commitments and evaluations, and return the challenges (plus "batch", the one that
-    folds the two opening checks).  t_eval: the verifier's own t(z); default = the prover's."""
+    folds the two opening checks).  t_eval: the verifier's own t(z); default = the prover's.  Labels and message
+    order come from the library's table (``transcript_labels``)."""
+    L = transcript_labels()
     ts = seeded_transcript(verifier_key, n, label)
     if bind_public_inputs:
         pos, val = public_inputs if isinstance(public_inputs, tuple) else sparse_public_inputs(public_inputs)
-        ts.append_u64(b"pi_len", len(pos))
+        ts.append_u64(L["pi_len"], len(pos))
         for p_, v_ in zip(pos, val):
-            ts.append_u64(b"pi_pos", int(p_))
-            ts.append_scalar(b"pi", v_)
-    for name, lab in zip("abcd", (b"w_l", b"w_r", b"w_o", b"w_4")):
-        ts.append_commitment(lab, proof.commitments[name])
-    ch = {"beta": ts.challenge_scalar(b"beta")}
-    ts.append_scalar(b"beta", fr_to_limbs(ch["beta"]))
-    ch["gamma"] = ts.challenge_scalar(b"gamma")
-    ts.append_commitment(b"z", proof.commitments["z"])
-    ch["alpha"] = ts.challenge_scalar(b"alpha")
-    ch["range_sep"] = ts.challenge_scalar(b"range separation challenge")
-    ch["logic_sep"] = ts.challenge_scalar(b"logic separation challenge")
-    ch["fixed_sep"] = ts.challenge_scalar(b"fixed base separation challenge")
-    ch["var_sep"] = ts.challenge_scalar(b"variable base separation challenge")
+            ts.append_u64(L["pi_pos"], int(p_))
+            ts.append_scalar(L["pi_value"], v_)
+    for j, name in enumerate("abcd"):
+        ts.append_commitment(L[f"wire_{j}"], proof.commitments[name])
+    ch = {"beta": ts.challenge_scalar(L["beta"])}
+    ts.append_scalar(L["beta"], fr_to_limbs(ch["beta"]))
+    ch["gamma"] = ts.challenge_scalar(L["gamma"])
+    ts.append_commitment(L["perm"], proof.commitments["z"])
+    ch["alpha"] = ts.challenge_scalar(L["alpha"])
+    ch["range_sep"] = ts.challenge_scalar(L["range_sep"])
+    ch["logic_sep"] = ts.challenge_scalar(L["logic_sep"])
+    ch["fixed_sep"] = ts.challenge_scalar(L["fixed_sep"])
+    ch["var_sep"] = ts.challenge_scalar(L["var_sep"])
     for i in range(4):
-        ts.append_commitment(f"t_{i + 1}".encode(), proof.commitments[f"t_{i + 1}"])
-    ch["z"] = ts.challenge_scalar(b"z")
-    for name in Proof.TRANSCRIPT_EVALS:
+        ts.append_commitment(L[f"quotient_{i}"], proof.commitments[f"t_{i + 1}"])
+    ch["z"] = ts.challenge_scalar(L["z_challenge"])
+    for i, name in enumerate(Proof.TRANSCRIPT_EVALS):
         v = proof.evaluations[name] if not (name == "t" and t_eval is not None) else fr_to_limbs(t_eval)
-        ts.append_scalar(_EVAL_LABELS[name], v)
-    ch["aw"] = ts.challenge_scalar(b"aggregate_witness")
-    ch["aw_shifted"] = ts.challenge_scalar(b"aggregate_witness")
-    ts.append_commitment(b"w_z", proof.commitments["w_z"])
-    ts.append_commitment(b"w_z_w", proof.commitments["w_zw"])
-    ch["batch"] = ts.challenge_scalar(b"batch")
+        ts.append_scalar(L[f"eval_{i}"], v)
+    ch["aw"] = ts.challenge_scalar(L["aggregate"])
+    ch["aw_shifted"] = ts.challenge_scalar(L["aggregate"])
+    ts.append_commitment(L["w_z"], proof.commitments["w_z"])
+    ts.append_commitment(L["w_zw"], proof.commitments["w_zw"])
+    ch["batch"] = ts.challenge_scalar(L["batch"])
     return ch
 
 

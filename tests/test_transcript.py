@@ -124,3 +124,21 @@ def test_commit_key_raw_bytes_roundtrip(oracle):
     for bad in (blob[:-1], blob[:5], blob + b"\0"):
         with pytest.raises(ValueError):
             srs.commit_key_from_raw_bytes(bad)
+
+
+def test_transcript_label_table_is_the_single_source():
+    """Both sides of Fiat-Shamir read ONE table (csrc/prover.hip, namespace tl, exported by pm_plonk_transcript_labels):
+    every message of a proof has its entry, in order, and the Python verifier side holds no label strings of its own."""
+    import inspect
+    import plonk_prototype_amd.prover as PR
+    L = PR.transcript_labels()
+    keys = list(L)
+    expect = (["protocol"] + [f"selector_{i}" for i in range(11)] + [f"sigma_{i}" for i in range(4)]
+              + ["dom_sep", "dom_sep_value", "circuit_size", "pi_len", "pi_pos", "pi_value"] + [f"wire_{i}" for i in range(4)]
+              + ["beta", "gamma", "perm", "alpha", "range_sep", "logic_sep", "fixed_sep", "var_sep"]
+              + [f"quotient_{i}" for i in range(4)] + ["z_challenge"] + [f"eval_{i}" for i in range(17)]
+              + ["aggregate", "w_z", "w_zw", "batch"])
+    assert keys == expect
+    assert L["protocol"] == b"plonk" and L["selector_9"] == b"q_variable_group_add" and L["eval_14"] == b"perm_eval"
+    src = inspect.getsource(PR.derive_challenges) + inspect.getsource(PR.seeded_transcript)
+    assert 'b"' not in src.split('"""', 2)[2].replace('b"abcd"', "")       # no byte-string labels outside the docstring
