@@ -373,6 +373,45 @@ int pm_plonk_prove(pm_ctx* ctx, pm_prover_key* key, const pm_bases* commit_key, 
                    pm_plonk_proof* out);
 /* Proof::to_bytes: 11 x 48-byte compressed G1, then the 16 scalars of ProofEvaluations::to_bytes. */
 int pm_plonk_proof_to_bytes(const pm_plonk_proof* proof, uint8_t out[PM_PLONK_PROOF_BYTES]);
+/* ---- The prover with coefficient-range ownership end to end (SURVEY.md section 8e row 3 + 8f N5; configs[4]) ----------
+ * pm_plonk_prove_sharded splits only the MSMs: every rank still holds every polynomial and repeats every transform.
+ * Here rank r of `world` (a power of two, world^2 <= n) owns rows / coefficients [r n / world, (r + 1) n / world) of
+ * every vector and nothing else -- workspace / world, no replicated transform: the size-n transforms run as
+ * pm_fr_ntt_fourstep_dev over the ranks (all-to-all), the 4n-coset work as four size-n sub-coset transforms, and prefix
+ * product, openings and Ruffini division are local passes plus one all-gather of per-rank scalars each.  The proof and
+ * the verifier key are bit-identical to pm_plonk_prove's on every rank.
+ *   allgather: gathers ONE fixed-size message per rank (PM_COMM_MSG_WORDS u64 words, host memory; word 0 = a count,
+ *              0 = the abort marker of a rank that gave up) into gathered[world][PM_COMM_MSG_WORDS]; returns 0 on success.
+ *              NULL = the context's RCCL communicator (pm_comm_init).  10 per proof (the first an agreement on the
+ *              arguments: public inputs, flags and size must be the same on every rank), 1 + 2 per key.
+ *   alltoall:  the callback of pm_fr_ntt_fourstep_dev (device buffers); NULL = the communicator.
+ * Inputs are the rank's slices: selector_slices[s] = m = n / world rows of selector s (NULL = identically zero on this
+ * rank), sigma_index_slices = [4][m] (wire j of row rank m + i is followed by position sigma_index, a GLOBAL index
+ * j' n + i'), commit_key_slice = powers [rank m, (rank + 1) m) of the commit key, d_witness_slices = [4][m] wire values
+ * in device memory.  Public inputs are passed whole (positions are global) on every rank.  A rank whose arguments are
+ * bad meets its peers in the agreement all-gather with the abort marker: every rank returns an error, nobody blocks.  A
+ * rank that fails later (a HIP error between two all-to-alls) returns its error and sends the marker to the next
+ * all-gather, but an all-to-all has no marker and no timeout: treat such an error as fatal for the group.
+ * pm_plonk_dist_key_bytes: device memory this rank holds for the key and its per-proof workspace. */
+#define PM_COMM_MSG_WORDS 289   /* 1 + 18 x PM_COMM_MAX_POINTS */
+typedef int (*pm_allgather_fn)(void* user, const uint64_t* msg, uint64_t* gathered);
+typedef struct pm_dist {
+  uint32_t world, rank;
+  pm_allgather_fn allgather;
+  pm_alltoall_fn alltoall;
+  void* user;
+} pm_dist;
+typedef struct pm_dist_key pm_dist_key;
+int pm_plonk_preprocess_dist(pm_ctx* ctx, const pm_dist* dist, const uint64_t* const selector_slices[PM_PLONK_SELECTORS],
+                             const int64_t* sigma_index_slices, size_t n, pm_dist_key** out);
+void pm_plonk_dist_key_free(pm_ctx* ctx, pm_dist_key* key);
+size_t pm_plonk_dist_key_bytes(const pm_dist_key* key);
+int pm_plonk_key_commit_dist(pm_ctx* ctx, const pm_dist* dist, pm_dist_key* key, const pm_bases* commit_key_slice,
+                             const char* transcript_label, uint64_t (*verifier_key_out)[12]);
+int pm_plonk_prove_dist(pm_ctx* ctx, const pm_dist* dist, pm_dist_key* key, const pm_bases* commit_key_slice,
+                        const void* d_witness_slices, const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi,
+                        uint32_t flags, pm_plonk_proof* out);
+
 /* Every label string of the transcript, in message order, as "key=label" lines (a static string).  The labels are
  * restated from the published dusk-plonk 0.8 design and are PARITY-UNPINNED; they live in ONE table (csrc/prover.hip,
  * namespace tl) that both the native prover and the Python verifier side read -- the single place to edit when

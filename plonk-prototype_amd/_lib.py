@@ -39,6 +39,16 @@ class PlonkProof(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint32)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, u64p)
+COMM_MSG_WORDS = 289
+
+
+class Dist(C.Structure):
+    """``pm_dist``"""
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("allgather", C.c_void_p), ("alltoall", C.c_void_p),
+                ("user", C.c_void_p)]
+
+
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 VK_POINTS = (C.c_uint64 * 12) * 15
 PLONK_SELECTORS, PLONK_PROOF_BYTES, PLONK_BIND_PUBLIC_INPUTS, PLONK_UPSTREAM_TRANSCRIPT = 11, 1040, 1, 2
@@ -110,6 +120,13 @@ SIGNATURES = {
     "pm_plonk_prove_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, u64p, u64p,
                                          C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(PlonkProof)]),
     "pm_plonk_transcript_labels": (C.c_char_p, []),
+    "pm_plonk_preprocess_dist": (C.c_int, [C.c_void_p, C.POINTER(Dist), C.POINTER(u64p), C.POINTER(C.c_int64), C.c_size_t,
+                                           C.POINTER(C.c_void_p)]),
+    "pm_plonk_dist_key_free": (None, [C.c_void_p, C.c_void_p]),
+    "pm_plonk_dist_key_bytes": (C.c_size_t, [C.c_void_p]),
+    "pm_plonk_key_commit_dist": (C.c_int, [C.c_void_p, C.POINTER(Dist), C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p]),
+    "pm_plonk_prove_dist": (C.c_int, [C.c_void_p, C.POINTER(Dist), C.c_void_p, C.c_void_p, C.c_void_p, u64p, u64p, C.c_size_t,
+                                      C.c_uint32, C.POINTER(PlonkProof)]),
     "pm_plonk_proof_to_bytes": (C.c_int, [C.POINTER(PlonkProof), C.POINTER(C.c_uint8)]),
     "pm_fr_poly_evaluate_many_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_size_t, u64p, u64p,
                                                C.c_void_p]),

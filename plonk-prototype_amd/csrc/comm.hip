@@ -61,7 +61,8 @@ static const ncclDataType_t kNcclUint64 = ncclUint64;
 
 // message of one rank: [count | PM_COMM_MAX_POINTS x 18 limbs]; count = 0 is the abort marker of a rank
 // whose local work failed (it still enters the collective, so no peer blocks)
-static constexpr size_t MSG_WORDS = 1 + 18 * (size_t)PM_COMM_MAX_POINTS;
+static constexpr size_t MSG_WORDS = COMM_MSG_WORDS;
+static_assert(COMM_MSG_WORDS == 1 + 18 * (size_t)PM_COMM_MAX_POINTS, "message = count + 16 points");
 
 // Fold what the ranks sent: out[j] = sum over ranks of point j.  -> PM_OK, or PM_ERR_EXCHANGE when a rank
 // sent the abort marker or the counts disagree.
@@ -161,22 +162,18 @@ extern "C" int pm_comm_info(const pm_ctx* ctx, int* rank, int* world) {
   return PM_OK;
 }
 
-// k = 0: this rank gave up (abort marker).  Returns PM_ERR_EXCHANGE on every rank if any rank did.
-extern "C" int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k) {
-  if (!ctx || (k && !xyz) || k > PM_COMM_MAX_POINTS) return PM_ERR_BAD_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+// All-gather of the fixed-size message on the context's communicator: gathered = world x COMM_MSG_WORDS words (host
+// memory).  msg[0] = 0 is the abort marker; a rank that cannot stage its message still enters the collective with it
+// (written by a memset), so that no peer waits in ncclAllGather for ever (it has no timeout).  The caller holds ctx->mu.
+int pm::comm_allgather_msg(pm_ctx* ctx, const uint64_t* msg, uint64_t* gathered) {
   if (!ctx->comm) return set_err(ctx, PM_ERR_EXCHANGE, "no communicator: pm_comm_init first");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   Rccl& r = rccl();
   const int world = ctx->comm_world;
   uint64_t* h_send = (uint64_t*)ctx->comm_host;
   uint64_t* h_recv = h_send + MSG_WORDS;
-  memset(h_send, 0, MSG_WORDS * 8);
-  h_send[0] = k;
-  if (k) memcpy(h_send + 1, xyz, 144 * (size_t)k);
+  memcpy(h_send, msg, MSG_WORDS * 8);
   hipStream_t st = ctx->stream;
-  // a rank that cannot stage its message still enters the collective -- with the abort marker (count 0), written by a
-  // memset if the copy failed -- so that no peer waits in ncclAllGather for ever (it has no timeout)
   bool staged = hipMemcpyAsync(ctx->comm_send, h_send, MSG_WORDS * 8, hipMemcpyHostToDevice, st) == hipSuccess;
   if (!staged) {
     (void)hipGetLastError();
@@ -187,8 +184,22 @@ extern "C" int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k) {
   PM_HIP(ctx, hipMemcpyAsync(h_recv, ctx->comm_recv, MSG_WORDS * 8 * (size_t)world, hipMemcpyDeviceToHost, st));
   PM_HIP(ctx, hipStreamSynchronize(st));
   if (!staged) return set_err(ctx, PM_ERR_EXCHANGE, "staging the exchange message failed: this rank aborted the exchange");
+  memcpy(gathered, h_recv, MSG_WORDS * 8 * (size_t)world);
+  return PM_OK;
+}
+
+// k = 0: this rank gave up (abort marker).  Returns PM_ERR_EXCHANGE on every rank if any rank did.
+extern "C" int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k) {
+  if (!ctx || (k && !xyz) || k > PM_COMM_MAX_POINTS) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->comm) return set_err(ctx, PM_ERR_EXCHANGE, "no communicator: pm_comm_init first");
+  std::vector<uint64_t> msg(MSG_WORDS, 0), gathered(MSG_WORDS * (size_t)ctx->comm_world);
+  msg[0] = k;
+  if (k) memcpy(msg.data() + 1, xyz, 144 * (size_t)k);
+  const int xrc = comm_allgather_msg(ctx, msg.data(), gathered.data());
+  if (xrc) return xrc;
   if (k == 0) return set_err(ctx, PM_ERR_EXCHANGE, "this rank aborted the exchange");
-  const int rc = fold_gathered(h_recv, world, k, xyz);
+  const int rc = fold_gathered(gathered.data(), ctx->comm_world, k, xyz);
   if (rc == PM_ERR_EXCHANGE) return set_err(ctx, rc, "a peer rank aborted the exchange (or sent a different count)");
   return rc;
 }

@@ -131,6 +131,13 @@ int ensure_buffer(pm_ctx* ctx, DeviceBuffer& b, size_t bytes);
 // with a per-context record, context B could lower what context A had set and A's next launch would fail).
 int raise_lds_limit(pm_ctx* ctx, const void* fn, size_t bytes);
 int comm_alltoall(pm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer, hipStream_t st);   // comm.hip
+// the fixed-size exchange message of the sharded / distributed prover: [count | 288 payload words]; count 0 = abort marker
+static constexpr size_t COMM_MSG_WORDS = 1 + 18 * (size_t)PM_COMM_MAX_POINTS;
+int comm_allgather_msg(pm_ctx* ctx, const uint64_t* msg, uint64_t* gathered);   // comm.hip; caller holds ctx->mu
+int fold_gathered(const uint64_t* msgs, int world, uint32_t k_local, uint64_t* out_xyz);   // comm.hip
+// quotient kernel over `rows` rows of the coset (4 rows points); halo: the arrays read at index + 4 (z, wires 0 1 3)
+// carry four more points after the last row instead of wrapping around (plonk_rounds.hip)
+int plonk_quotient_rows(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t rows, bool halo, void* d_out, void* hip_stream);
 struct OrderScope {
   pm_ctx* ctx;
   StreamOrder& o;

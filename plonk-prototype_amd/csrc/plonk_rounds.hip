@@ -154,7 +154,7 @@ PM_DEV Fr wdelta(const Fr& f, const WidgetConsts& c) {
 
 template <bool WIDGETS>
 __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, const RoundConsts kc, const WidgetConsts wc,
-                                                       size_t n4) {
+                                                       size_t n4, size_t wrap) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;   // a multiple of 4: i mod 4 is fixed per thread
   const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 r4 = (u32)(t0 & 3);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
     zhi.l[l] = r4 == 0 ? kc.zh_inv[0][l] : (r4 == 1 ? kc.zh_inv[1][l] : (r4 == 2 ? kc.zh_inv[2][l] : kc.zh_inv[3][l]));
   const Fr gamma = fr_limbs(kc.gamma);
   for (size_t i = t0; i < n4; i += stride) {
-    const size_t inext = i + 4 < n4 ? i + 4 : i + 4 - n4;
+    const size_t inext = i + 4 < wrap ? i + 4 : i + 4 - wrap;   // wrap = n4, or n4 + 4 when the rows carry a halo
     Fr w[4], f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = to_dev(ld_canon(p.w[j], i));
@@ -359,6 +359,10 @@ extern "C" int pm_plonk_perm_terms_dev(pm_ctx* ctx, const pm_plonk_perm_args* ar
 
 extern "C" int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, void* d_out,
                                      void* hip_stream) {
+  return pm::plonk_quotient_rows(ctx, args, n, false, d_out, hip_stream);
+}
+int pm::plonk_quotient_rows(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, bool halo, void* d_out,
+                            void* hip_stream) {
   if (!ctx) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!args) return set_err(ctx, PM_ERR_BAD_ARG, "null args");
@@ -420,9 +424,11 @@ extern "C" int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* 
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   ProfScope prof(ctx, st, "plonk_quotient");
   if (widgets)
-    hipLaunchKernelGGL(quotient_kernel<true>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n);
+    hipLaunchKernelGGL(quotient_kernel<true>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n,
+                       4 * n + (halo ? 4 : 0));
   else
-    hipLaunchKernelGGL(quotient_kernel<false>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n);
+    hipLaunchKernelGGL(quotient_kernel<false>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n,
+                       4 * n + (halo ? 4 : 0));
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
 }

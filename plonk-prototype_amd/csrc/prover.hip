@@ -972,3 +972,5 @@ extern "C" int pm_plonk_verifier_key(const pm_prover_key* key, uint64_t (*out)[1
   memcpy(out, key->vk, sizeof key->vk);
   return PM_OK;
 }
+
+#include "prover_dist.hip.h"

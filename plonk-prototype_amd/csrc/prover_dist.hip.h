@@ -1,0 +1,690 @@
+// The prover with COEFFICIENT-RANGE OWNERSHIP END TO END (SURVEY.md section 8e row 3 + section 8f N5; BASELINE.json configs[4]):
+// included at the end of prover.hip (it shares the transcript, the widget scalars and the label table with the
+// single-GPU prover -- both must produce the same bytes).
+//
+// pm_plonk_prove_sharded replicates every transform, the quotient and the openings on all ranks and only splits the MSMs;
+// at 2^24 gates that is ~70 GB of workspace per rank and an Amdahl floor of ~16 % of a proof.  Here rank r of W owns
+//     rows    [r m, (r + 1) m)  of every evaluation vector over H          (m = n / W)
+//     coefficients [r m, (r + 1) m) of every polynomial -- the range its slice of the commit key commits to
+//     points  k in [r m, (r + 1) m) of each of the four sub-cosets  g w4^s H  (s = 0 .. 3) of the 4n coset
+// and nothing else: workspace / W, no replicated transform.  What the single-GPU prover does with a size-4n coset
+// transform of a degree < n polynomial is four size-n transforms here (the 4n coset g <w4> is the union of the sub-cosets
+// g_s H, g_s = g w4^s: f(g_s w^k) = NTT_n(f_i g_s^i)[k]), each one pm_fr_ntt_fourstep_dev over the ranks (the all-to-all of
+// section 7.5); the quotient kernel runs on the rank's rows in the same interleaved order (index 4 k + s) as on one GPU,
+// with a four-point halo from the next rank for z(w X) and the next-row wires; the quotient's coefficients come back
+// through four inverse transforms and a pointwise 4-point inverse DFT; prefix product, openings and Ruffini division
+// are local passes plus one fixed-size all-gather of per-rank scalars each.  Every exchange besides the all-to-all is
+// the SAME 2312-byte message all-gather as the sharded prover's (count word 0 = abort marker): 10 per proof, the first an
+// agreement on the arguments: a rank whose arguments are bad meets its peers there with the marker.  (A rank that fails
+// LATER, between two all-to-alls -- a HIP error, an allocation -- returns its error; its peers see the marker at their next
+// all-gather but cannot see it inside an all-to-all: treat such an error as fatal for the group.)
+// Results are bit-identical to pm_plonk_prove (tests/test_gpu_dist_prover_n5.py).
+
+struct pm_dist_key {
+  size_t n = 0, m = 0, lo = 0;
+  uint32_t log_n = 0, world = 1, rank = 0;
+  HFr omega, k[3], zh_inv[4], gs[4];
+  // device arrays (element counts in units of m = n / world)
+  void *roots = nullptr /* m */, *x4 = nullptr /* 4m */, *gs_pow = nullptr /* 4m: g_s^i */, *gs_inv_pow = nullptr /* 4m */,
+       *sel_coeffs = nullptr /* 11m */, *sigma_evals = nullptr /* 4m */, *sigma_coeffs = nullptr /* 4m */,
+       *sigma_coset = nullptr /* 16m */, *l1_coset = nullptr /* 4m */;
+  void* sel_coset[NSEL] = {};
+  bool sel_zero[NSEL] = {};
+  bool arith_is_one = false;
+  // per-proof workspace: coeffs [a b c d z pi] 6m | num m | den m | coset 6 (4m + 4) | t 4m | tq 4m | r m | agg 2m | wit 2m |
+  // pi m | stage 2m | tmp 4m | one scalar
+  void *coeffs = nullptr, *num = nullptr, *den = nullptr, *coset = nullptr, *t = nullptr, *tq = nullptr, *r = nullptr,
+       *agg = nullptr, *wit = nullptr, *pi_evals = nullptr, *stage = nullptr, *tmp = nullptr, *scalar = nullptr;
+  size_t device_bytes = 0;   // what this rank holds for the key and its workspace
+  bool committed = false;
+  u64 vk[NSEL + 4][12] = {};
+  Transcript base{std::string("plonk")};
+  std::atomic<bool> busy{false};
+};
+
+namespace {
+struct Dist {
+  pm_dist d;
+  int expect = 0;          // message all-gathers the call makes on every rank
+  int done = 0;
+  bool aborted = false;
+};
+// One all-gather of the fixed-size message; msg[0] = count (0 = abort marker).  gathered: world x COMM_MSG_WORDS.
+int dist_exchange(pm_ctx* ctx, Dist& D, const std::vector<u64>& msg, std::vector<u64>& gathered) {
+  gathered.assign(pm::COMM_MSG_WORDS * (size_t)D.d.world, 0);
+  int rc;
+  if (D.d.allgather) {
+    rc = D.d.allgather(D.d.user, msg.data(), gathered.data()) != 0 ? PM_ERR_EXCHANGE : PM_OK;
+  } else {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->comm || ctx->comm_world != (int)D.d.world || ctx->comm_rank != (int)D.d.rank)
+      rc = pm::set_err(ctx, PM_ERR_EXCHANGE, "no all-gather callback and no matching communicator (pm_comm_init)");
+    else
+      rc = pm::comm_allgather_msg(ctx, msg.data(), gathered.data());
+  }
+  ++D.done;
+  if (rc == PM_OK && msg[0] == 0) rc = PM_ERR_EXCHANGE;
+  for (uint32_t r = 0; r < D.d.world && rc == PM_OK; ++r)
+    if (gathered[r * pm::COMM_MSG_WORDS] != msg[0]) rc = PM_ERR_EXCHANGE;   // a peer gave up, or the ranks are out of step
+  if (rc != PM_OK) D.aborted = true;
+  return rc;
+}
+int dist_leave(pm_ctx* ctx, Dist& D, int rc) {
+  if (rc != PM_OK && ctx && !D.aborted && D.done < D.expect) {
+    std::vector<u64> msg(pm::COMM_MSG_WORDS, 0), g;
+    (void)dist_exchange(ctx, D, msg, g);
+  }
+  return rc;
+}
+// k <= 16 partial points -> their sums over the ranks
+int dist_points(pm_ctx* ctx, Dist& D, u64* xyz, uint32_t k) {
+  std::vector<u64> msg(pm::COMM_MSG_WORDS, 0), g;
+  msg[0] = k;
+  memcpy(msg.data() + 1, xyz, 144 * (size_t)k);
+  PK_TRY(dist_exchange(ctx, D, msg, g));
+  return pm::fold_gathered(g.data(), (int)D.d.world, k, xyz);
+}
+// k <= 72 scalars per rank -> all[rank][j]
+int dist_scalars(pm_ctx* ctx, Dist& D, const HFr* vals, uint32_t k, std::vector<HFr>& all) {
+  std::vector<u64> msg(pm::COMM_MSG_WORDS, 0), g;
+  msg[0] = k;
+  for (uint32_t j = 0; j < k; ++j) memcpy(msg.data() + 1 + 4 * j, vals[j].l, 32);
+  PK_TRY(dist_exchange(ctx, D, msg, g));
+  all.resize((size_t)D.d.world * k);
+  for (uint32_t r = 0; r < D.d.world; ++r)
+    for (uint32_t j = 0; j < k; ++j) memcpy(all[(size_t)r * k + j].l, g.data() + r * pm::COMM_MSG_WORDS + 1 + 4 * j, 32);
+  return PM_OK;
+}
+HFr fpow64(const HFr& a, u64 e) { return fpow(a, e); }
+
+// one size-n transform over the ranks, in place on this rank's m-element block (natural order in and out)
+int dist_ntt(pm_ctx* ctx, const Dist& D, const pm_dist_key* pk, void* d_block, uint32_t flags) {
+  return pm_fr_ntt_fourstep_dev(ctx, d_block, pk->stage, pk->log_n, D.d.world, D.d.rank, flags, D.d.alltoall, D.d.user);
+}
+// rows [4 k + s] <- src[k]: the interleaved order of the 4n coset
+int interleave(pm_ctx* ctx, void* d_il, int s, const void* d_src, size_t m) {
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  PM_HIP(ctx, hipMemcpy2DAsync((char*)d_il + 32 * s, 128, d_src, 32, 32, m, hipMemcpyDeviceToDevice, ctx->stream));
+  return PM_OK;
+}
+int deinterleave(pm_ctx* ctx, void* d_dst, const void* d_il, int s, size_t m) {
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  PM_HIP(ctx, hipMemcpy2DAsync(d_dst, 32, (const char*)d_il + 32 * s, 128, 32, m, hipMemcpyDeviceToDevice, ctx->stream));
+  return PM_OK;
+}
+// coefficients [lo, lo + m) of a polynomial of degree < n  ->  its values on the rank's points of the four sub-cosets,
+// interleaved ([4 k + s], k local): four size-n transforms over the ranks
+int dist_to_coset(pm_ctx* ctx, const Dist& D, const pm_dist_key* pk, const void* d_coeffs, void* d_il) {
+  const size_t m = pk->m;
+  for (int s = 0; s < 4; ++s) {
+    PK_TRY(pm_fr_vec_op_dev(ctx, 2, d_coeffs, at(pk->gs_pow, s * m), m, pk->tmp, m, nullptr));
+    PK_TRY(dist_ntt(ctx, D, pk, pk->tmp, 0));
+    PK_TRY(interleave(ctx, d_il, s, pk->tmp, m));
+  }
+  return PM_OK;
+}
+int upload_scalar(pm_ctx* ctx, const pm_dist_key* pk, const HFr& v) {
+  PK_TRY(pm_sync(ctx));   // the previous user of the one-scalar buffer has finished
+  return pm_dev_upload(ctx, pk->scalar, v.l, 32);
+}
+int commit_batch_dist(pm_ctx* ctx, Dist& D, const pm_dist_key* pk, const pm_bases* ck, const void* d, size_t n_coeffs,
+                      uint32_t batch, u64 (*out_xy)[12]) {
+  u64 xyz[16 * 18];
+  if (batch > 16) return PM_ERR_BAD_ARG;
+  const size_t hi = std::min(pk->lo + pk->m, n_coeffs);
+  const size_t cnt = hi > pk->lo ? hi - pk->lo : 0;
+  int rc = PM_OK;
+  if (cnt > 0) {
+    rc = pm_g1_msm_batch_dev(ctx, ck, 0, cnt, d, pk->m, batch, PM_SCALAR_MONTGOMERY, xyz, nullptr);
+  } else {
+    memset(xyz, 0, sizeof xyz);
+    for (uint32_t b = 0; b < batch; ++b) memcpy(xyz + 18 * b + 6, pm::host::FP().one, 48);   // (0, 1, 0)
+  }
+  if (rc != PM_OK) return rc;   // dist_leave sends the abort marker
+  PK_TRY(dist_points(ctx, D, xyz, batch));
+  return pm_g1_to_affine_batch(xyz, batch, &out_xy[0][0], nullptr);
+}
+struct DistBusy {
+  pm_dist_key* pk;
+  bool ok;
+  explicit DistBusy(pm_dist_key* k) : pk(k), ok(!k->busy.exchange(true)) {}
+  ~DistBusy() {
+    if (ok) pk->busy.store(false);
+  }
+};
+int dist_check(const pm_dist* d, size_t n) {
+  if (!d || d->world == 0 || (d->world & (d->world - 1)) || d->rank >= d->world) return PM_ERR_BAD_ARG;
+  if (n < 4 || (n & (n - 1))) return PM_ERR_LENGTH;
+  uint32_t lg = 0;
+  while (((size_t)1 << lg) < n) ++lg;
+  if (lg > 26) return PM_ERR_DOMAIN_TOO_LARGE;
+  if (((size_t)1 << (lg / 2)) % d->world) return PM_ERR_BAD_ARG;   // the ranks must divide both factors of the size-n transform
+  return PM_OK;
+}
+}  // namespace
+
+extern "C" void pm_plonk_dist_key_free(pm_ctx* ctx, pm_dist_key* pk) {
+  if (!pk) return;
+  if (ctx) (void)pm_sync(ctx);
+  for (void* p : {pk->roots, pk->x4, pk->gs_pow, pk->gs_inv_pow, pk->sel_coeffs, pk->sigma_evals, pk->sigma_coeffs, pk->sigma_coset,
+                  pk->l1_coset, pk->coeffs, pk->num, pk->den, pk->coset, pk->t, pk->tq, pk->r, pk->agg, pk->wit, pk->pi_evals,
+                  pk->stage, pk->tmp, pk->scalar})
+    if (p && ctx) (void)pm_dev_free(ctx, p);
+  for (void* p : pk->sel_coset)
+    if (p && ctx) (void)pm_dev_free(ctx, p);
+  delete pk;
+}
+extern "C" size_t pm_plonk_dist_key_bytes(const pm_dist_key* key) { return key ? key->device_bytes : 0; }
+
+static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uint64_t* const selector_slices[PM_PLONK_SELECTORS],
+                                const int64_t* sigma_index_slices) {
+  const size_t n = pk->n, m = pk->m, lo = pk->lo;
+  const uint32_t lg = pk->log_n;
+  u64 w[4], wi[4], si[4], w4[4];
+  PK_TRY(pm_domain_info(lg, w, wi, si));
+  PK_TRY(pm_domain_info(lg + 2, w4, wi, wi));
+  pk->omega = get(w);
+  const HFr n_inv = get(si), omega4 = get(w4), one = fone(), g = fr_u64(7), zero = pm::host::zero<4>();
+  pk->k[0] = fr_u64(7);
+  pk->k[1] = fr_u64(13);
+  pk->k[2] = fr_u64(17);
+  {
+    HFr p = g;
+    for (int s = 0; s < 4; ++s) {
+      pk->gs[s] = p;
+      p = fmul(p, omega4);
+    }
+  }
+  // trivial selector polynomials: a GLOBAL property (every rank must take the same branches): local flags, one exchange
+  {
+    HFr flags[3] = {zero, zero, zero};   // words: [selector non-zero mask, q_arith differs from one, rank | world << 32 | n << 40]
+    u64 nz = 0, not_one = selector_slices[Q_ARITH] ? 0 : 1;
+    for (int s = 0; s < NSEL; ++s)
+      if (selector_slices[s])
+        for (size_t i = 0; i < 4 * m; ++i)
+          if (selector_slices[s][i]) {
+            nz |= (u64)1 << s;
+            break;
+          }
+    if (selector_slices[Q_ARITH])
+      for (size_t i = 0; i < m && !not_one; ++i) not_one = memcmp(selector_slices[Q_ARITH] + 4 * i, one.l, 32) != 0;
+    flags[0].l[0] = nz;
+    flags[0].l[1] = not_one;
+    flags[0].l[2] = D.d.rank;
+    flags[0].l[3] = (u64)n;
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, flags, 1, all));
+    u64 nz_all = 0, not_one_all = 0, seen = 0;
+    for (uint32_t r = 0; r < D.d.world; ++r) {
+      nz_all |= all[r].l[0];
+      not_one_all |= all[r].l[1];
+      if (all[r].l[2] < 64) seen |= (u64)1 << all[r].l[2];
+      if (all[r].l[3] != (u64)n) return pm::set_err(ctx, PM_ERR_LENGTH, "the ranks disagree on the circuit size");
+    }
+    if (D.d.world <= 64 && seen != (D.d.world == 64 ? ~(u64)0 : (((u64)1 << D.d.world) - 1)))
+      return pm::set_err(ctx, PM_ERR_BAD_ARG, "the ranks of the group are not 0 .. world - 1, each once");
+    for (int s = 0; s < NSEL; ++s) pk->sel_zero[s] = !((nz_all >> s) & 1);
+    pk->arith_is_one = !not_one_all;
+  }
+  struct Alloc { void** p; size_t elems; };
+  std::vector<Alloc> allocs = {{&pk->roots, m},        {&pk->x4, 4 * m},          {&pk->gs_pow, 4 * m},      {&pk->gs_inv_pow, 4 * m},
+                               {&pk->sel_coeffs, (size_t)NSEL * m},               {&pk->sigma_evals, 4 * m}, {&pk->sigma_coeffs, 4 * m},
+                               {&pk->sigma_coset, 16 * m}, {&pk->l1_coset, 4 * m}, {&pk->coeffs, 6 * m},      {&pk->num, m},
+                               {&pk->den, m},          {&pk->coset, 6 * (4 * m + 4)}, {&pk->t, 4 * m},        {&pk->tq, 4 * m},
+                               {&pk->r, m},            {&pk->agg, 2 * m},         {&pk->wit, 2 * m},         {&pk->pi_evals, m},
+                               {&pk->stage, 2 * m},    {&pk->tmp, 4 * m},         {&pk->scalar, 1}};
+  for (int s = 0; s < NSEL; ++s) {
+    const bool need = s <= Q_4 || (s == Q_ARITH ? !pk->arith_is_one : !pk->sel_zero[s]);
+    if (need) allocs.push_back({&pk->sel_coset[s], 4 * m});
+  }
+  for (const Alloc& a : allocs) {
+    PK_TRY(pm_dev_alloc(ctx, a.elems * 32, a.p));
+    pk->device_bytes += a.elems * 32;
+  }
+  // this rank's domain points, sub-coset powers g_s^i (i global) and the coset points x = g_s w^k in interleaved order
+  PK_TRY(pm_fr_powers_dev(ctx, pk->omega.l, fpow64(pk->omega, lo).l, m, pk->roots, nullptr));
+  for (int s = 0; s < 4; ++s) {
+    const HFr gi = finv(pk->gs[s]);
+    PK_TRY(pm_fr_powers_dev(ctx, pk->gs[s].l, fpow64(pk->gs[s], lo).l, m, at(pk->gs_pow, s * m), nullptr));
+    PK_TRY(pm_fr_powers_dev(ctx, gi.l, fpow64(gi, lo).l, m, at(pk->gs_inv_pow, s * m), nullptr));
+    PK_TRY(pm_fr_powers_dev(ctx, pk->omega.l, fmul(pk->gs[s], fpow64(pk->omega, lo)).l, m, pk->tmp, nullptr));
+    PK_TRY(interleave(ctx, pk->x4, s, pk->tmp, m));
+  }
+  // selectors: rows -> coefficient slices -> the coset forms the quotient kernel reads
+  for (int s = 0; s < NSEL; ++s) {
+    void* dst = at(pk->sel_coeffs, s * m);
+    if (pk->sel_zero[s] || !selector_slices[s]) {
+      PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, m, dst, nullptr));
+      if (pk->sel_zero[s]) continue;
+    } else {
+      PK_TRY(pm_dev_upload(ctx, dst, selector_slices[s], m * 32));
+    }
+    PK_TRY(dist_ntt(ctx, D, pk, dst, PM_NTT_INVERSE));
+    if (pk->sel_coset[s]) PK_TRY(dist_to_coset(ctx, D, pk, dst, pk->sel_coset[s]));
+  }
+  // sigma_j(w^i) = k_j' w^i' for this rank's rows: two-level host tables of w (2 sqrt(n) entries) instead of n roots
+  {
+    const uint32_t h = (lg + 1) / 2;
+    const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (lg - h);
+    std::vector<HFr> tlo(nlo), thi(nhi);
+    tlo[0] = one;
+    for (size_t i = 1; i < nlo; ++i) tlo[i] = fmul(tlo[i - 1], pk->omega);
+    const HFr step = fmul(tlo[nlo - 1], pk->omega);
+    thi[0] = one;
+    for (size_t i = 1; i < nhi; ++i) thi[i] = fmul(thi[i - 1], step);
+    const HFr ks[4] = {one, pk->k[0], pk->k[1], pk->k[2]};
+    std::vector<u64> vals(16 * m);
+    for (size_t p = 0; p < 4 * m; ++p) {
+      const int64_t q = sigma_index_slices[p];
+      if (q < 0 || (size_t)q >= 4 * n) return pm::set_err(ctx, PM_ERR_BAD_ARG, "sigma index outside the circuit");
+      const size_t jj = (size_t)q / n, ii = (size_t)q % n;
+      const HFr v = fmul(ks[jj], fmul(thi[ii >> h], tlo[ii & (nlo - 1)]));
+      memcpy(&vals[4 * p], v.l, 32);
+    }
+    PK_TRY(pm_dev_upload(ctx, pk->sigma_evals, vals.data(), 4 * m * 32));
+  }
+  for (int j = 0; j < 4; ++j) {
+    void* cj = at(pk->sigma_coeffs, j * m);
+    PM_HIP(ctx, hipMemcpyAsync(cj, at(pk->sigma_evals, j * m), m * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    PK_TRY(dist_ntt(ctx, D, pk, cj, PM_NTT_INVERSE));
+    PK_TRY(dist_to_coset(ctx, D, pk, cj, at(pk->sigma_coset, 4 * m * j)));
+  }
+  // L_1 = (1/n) sum X^i on the coset
+  PK_TRY(pm_fr_powers_dev(ctx, one.l, n_inv.l, m, pk->num, nullptr));
+  PK_TRY(dist_to_coset(ctx, D, pk, pk->num, pk->l1_coset));
+  PK_TRY(pm_sync(ctx));
+  {
+    const HFr gn = fpow(g, n), i4 = fpow(omega4, n);
+    HFr p = one;
+    for (int k = 0; k < 4; ++k) {
+      pk->zh_inv[k] = finv(fsub(fmul(gn, p), one));
+      p = fmul(p, i4);
+    }
+  }
+  return PM_OK;
+}
+
+extern "C" int pm_plonk_preprocess_dist(pm_ctx* ctx, const pm_dist* dist, const uint64_t* const selector_slices[PM_PLONK_SELECTORS],
+                                        const int64_t* sigma_index_slices, size_t n, pm_dist_key** out) {
+  if (!ctx || !dist || !selector_slices || !sigma_index_slices || !out) return PM_ERR_BAD_ARG;
+  *out = nullptr;
+  Dist D;
+  D.d = *dist;
+  D.expect = 1;
+  int rc = dist_check(dist, n);
+  if (rc) return rc;   // a malformed group or size is the same on every rank: nothing to tell the peers
+  pm_dist_key* pk = new pm_dist_key();
+  pk->n = n;
+  pk->world = dist->world;
+  pk->rank = dist->rank;
+  pk->m = n / dist->world;
+  pk->lo = pk->m * dist->rank;
+  while (((size_t)1 << pk->log_n) < n) ++pk->log_n;
+  rc = preprocess_dist_body(ctx, D, pk, selector_slices, sigma_index_slices);
+  rc = dist_leave(ctx, D, rc);
+  if (rc) {
+    pm_plonk_dist_key_free(ctx, pk);
+    return rc;
+  }
+  *out = pk;
+  return PM_OK;
+}
+
+extern "C" int pm_plonk_key_commit_dist(pm_ctx* ctx, const pm_dist* dist, pm_dist_key* pk, const pm_bases* ck_slice,
+                                        const char* transcript_label, uint64_t (*vk_out)[12]) {
+  if (!ctx || !dist || !pk || !ck_slice) return PM_ERR_BAD_ARG;
+  Dist D;
+  D.d = *dist;
+  D.expect = 2;
+  auto body = [&]() -> int {
+    if (dist->world != pk->world || dist->rank != pk->rank) return PM_ERR_BAD_ARG;
+    if (pm_g1_bases_len(ck_slice) < pk->m) return PM_ERR_LENGTH;   // powers [rank m, (rank + 1) m) of the commit key
+    PK_TRY(commit_batch_dist(ctx, D, pk, ck_slice, pk->sel_coeffs, pk->n, NSEL, &pk->vk[0]));
+    PK_TRY(commit_batch_dist(ctx, D, pk, ck_slice, pk->sigma_coeffs, pk->n, 4, &pk->vk[NSEL]));
+    Transcript ts(transcript_label ? transcript_label : tl::PROTOCOL);
+    for (int i = 0; i < NSEL; ++i) ts.append_commitment(SEL_LABELS[i], pk->vk[SEL_SEED_ORDER[i]]);
+    for (int j = 0; j < 4; ++j) ts.append_commitment(SIGMA_LABELS[j], pk->vk[NSEL + j]);
+    ts.append(tl::DOM_SEP, (const uint8_t*)tl::DOM_SEP_VALUE, strlen(tl::DOM_SEP_VALUE));
+    ts.append_u64(tl::CIRCUIT_SIZE, pk->n);
+    pk->base = ts;
+    pk->committed = true;
+    if (vk_out) memcpy(vk_out, pk->vk, sizeof pk->vk);
+    return PM_OK;
+  };
+  return dist_leave(ctx, D, body());
+}
+
+static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases* ck, const void* d_witness,
+                           const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
+                           pm_plonk_proof* out) {
+  if (!pk || !ck || !d_witness || !out) return PM_ERR_BAD_ARG;
+  if (D.d.world != pk->world || D.d.rank != pk->rank) return PM_ERR_BAD_ARG;
+  if (n_pi && (!pi_positions || !pi_values)) return PM_ERR_BAD_ARG;
+  if (flags & ~(PM_PLONK_BIND_PUBLIC_INPUTS | PM_PLONK_UPSTREAM_TRANSCRIPT)) return PM_ERR_BAD_ARG;
+  if (flags == (PM_PLONK_BIND_PUBLIC_INPUTS | PM_PLONK_UPSTREAM_TRANSCRIPT)) return PM_ERR_BAD_ARG;
+  if (!pk->committed) return PM_ERR_BAD_ARG;
+  DistBusy guard(pk);
+  if (!guard.ok) return PM_ERR_BUSY;
+  const size_t n = pk->n, m = pk->m, lo = pk->lo;
+  const uint32_t W = pk->world, rk = pk->rank;
+  if (pm_g1_bases_len(ck) < m) return PM_ERR_LENGTH;
+  for (size_t i = 0; i < n_pi; ++i)
+    if (pi_positions[i] >= n) return PM_ERR_LENGTH;
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  {
+    // agreement: every rank has checked its arguments by now -- a rank whose check failed returns above and dist_leave sends
+    // the abort marker HERE, before its peers enter the first all-to-all (ncclSend / ncclRecv carry no marker and have no
+    // timeout).  The message also pins the statement: every rank must have been given the same public inputs and flags.
+    HFr sum = pm::host::zero<4>();
+    u64 h = 0x9e3779b97f4a7c15ULL ^ flags ^ ((u64)n_pi << 8);
+    for (size_t i = 0; i < n_pi; ++i) {
+      h = (h ^ pi_positions[i]) * 0xbf58476d1ce4e5b9ULL;
+      for (int l = 0; l < 4; ++l) h = (h ^ pi_values[4 * i + l]) * 0x94d049bb133111ebULL + (h >> 29);
+    }
+    sum.l[0] = h;
+    sum.l[1] = n;
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, &sum, 1, all));
+    for (uint32_t r = 0; r < W; ++r)
+      if (all[r].l[0] != h || all[r].l[1] != (u64)n)
+        return pm::set_err(ctx, PM_ERR_BAD_ARG, "the ranks were given different public inputs, flags or circuit sizes");
+  }
+  Transcript ts = pk->base;
+  if (!(flags & PM_PLONK_UPSTREAM_TRANSCRIPT)) {
+    ts.append_u64(tl::PI_LEN, n_pi);
+    for (size_t i = 0; i < n_pi; ++i) {
+      ts.append_u64(tl::PI_POS, pi_positions[i]);
+      ts.append_scalar(tl::PI_VALUE, get(pi_values + 4 * i));
+    }
+  }
+  const HFr one = fone();
+  const size_t cs = 4 * m + 4;   // a coset array with its halo
+  auto coset = [&](int j) { return at(pk->coset, cs * j); };
+  // ---- round 1 --------------------------------------------------------------------------------
+  PM_HIP(ctx, hipMemcpyAsync(pk->coeffs, d_witness, 4 * m * 32, hipMemcpyDeviceToDevice, st));
+  for (int j = 0; j < 4; ++j) PK_TRY(dist_ntt(ctx, D, pk, at(pk->coeffs, j * m), PM_NTT_INVERSE));
+  void* pi_coeffs = at(pk->coeffs, 5 * m);
+  PM_HIP(ctx, hipMemsetAsync(pi_coeffs, 0, m * 32, st));
+  for (size_t i = 0; i < n_pi; ++i)   // a repeated position keeps its last value (stream order)
+    if (pi_positions[i] >= lo && pi_positions[i] < lo + m)
+      PM_HIP(ctx, hipMemcpyAsync(at(pi_coeffs, pi_positions[i] - lo), pi_values + 4 * i, 32, hipMemcpyHostToDevice, st));
+  PM_HIP(ctx, hipStreamSynchronize(st));   // pi_values is the caller's memory
+  PK_TRY(dist_ntt(ctx, D, pk, pi_coeffs, PM_NTT_INVERSE));
+  for (int j = 0; j < 4; ++j) PK_TRY(dist_to_coset(ctx, D, pk, at(pk->coeffs, j * m), coset(j)));
+  PK_TRY(dist_to_coset(ctx, D, pk, pi_coeffs, coset(5)));
+  PK_TRY(commit_batch_dist(ctx, D, pk, ck, pk->coeffs, n, 4, &out->commitments[0]));
+  for (int j = 0; j < 4; ++j) ts.append_commitment(tl::WIRES[j], out->commitments[j]);
+  // ---- round 2 --------------------------------------------------------------------------------
+  const HFr beta = ts.challenge_scalar(tl::BETA);
+  ts.append_scalar(tl::BETA, beta);
+  const HFr gamma = ts.challenge_scalar(tl::GAMMA);
+  pm_plonk_perm_args pa;
+  memset(&pa, 0, sizeof pa);
+  for (int j = 0; j < 4; ++j) {
+    pa.wires[j] = at((void*)d_witness, j * m);
+    pa.sigmas[j] = at(pk->sigma_evals, j * m);
+  }
+  pa.roots = pk->roots;
+  put(pa.beta, beta);
+  put(pa.gamma, gamma);
+  for (int j = 0; j < 3; ++j) put(pa.k[j], pk->k[j]);
+  PK_TRY(pm_plonk_perm_terms_dev(ctx, &pa, m, pk->num, pk->den, nullptr));
+  PK_TRY(pm_fr_batch_inverse_dev(ctx, pk->den, m, nullptr));
+  PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->num, pk->den, m, pk->num, m, nullptr));
+  PK_TRY(pm_fr_prefix_product_dev(ctx, pk->num, m, pk->den, nullptr));   // den[i] = product of this rank's num[0 .. i)
+  {
+    // the product of the whole slice = den[m - 1] num[m - 1]; every rank's goes round, the ranks below give the carry
+    u64 last[2][4];
+    PK_TRY(pm_dev_download(ctx, last[0], at(pk->den, m - 1), 32));
+    PK_TRY(pm_dev_download(ctx, last[1], at(pk->num, m - 1), 32));
+    const HFr total = fmul(get(last[0]), get(last[1]));
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, &total, 1, all));
+    HFr carry = one;
+    for (uint32_t r = 0; r < rk; ++r) carry = fmul(carry, all[r]);
+    PK_TRY(upload_scalar(ctx, pk, carry));
+    PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->den, pk->scalar, 1, pk->den, m, nullptr));
+  }
+  void* z_coeffs = at(pk->coeffs, 4 * m);
+  PM_HIP(ctx, hipMemcpyAsync(z_coeffs, pk->den, m * 32, hipMemcpyDeviceToDevice, st));
+  PK_TRY(dist_ntt(ctx, D, pk, z_coeffs, PM_NTT_INVERSE));
+  PK_TRY(dist_to_coset(ctx, D, pk, z_coeffs, coset(4)));
+  PK_TRY(commit_batch_dist(ctx, D, pk, ck, z_coeffs, n, 1, &out->commitments[4]));
+  ts.append_commitment(tl::PERM, out->commitments[4]);
+  // ---- round 3 --------------------------------------------------------------------------------
+  const HFr alpha = ts.challenge_scalar(tl::ALPHA);
+  const HFr range_sep = ts.challenge_scalar(tl::RANGE_SEP);
+  const HFr logic_sep = ts.challenge_scalar(tl::LOGIC_SEP);
+  const HFr fixed_sep = ts.challenge_scalar(tl::FIXED_SEP);
+  const HFr var_sep = ts.challenge_scalar(tl::VAR_SEP);
+  {
+    // halo: what the quotient kernel reads at index + 4 past this rank's last row = the next rank's first row
+    // (the last rank wraps to the first): z and the wires a, b, d -- 16 scalars per rank, one exchange
+    const int halo_of[4] = {4, 0, 1, 3};
+    HFr first[16];
+    for (int a = 0; a < 4; ++a) PK_TRY(pm_dev_download(ctx, first[4 * a].l, coset(halo_of[a]), 128));
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, first, 16, all));
+    const HFr* nxt = &all[(size_t)((rk + 1) % W) * 16];
+    for (int a = 0; a < 4; ++a) PK_TRY(pm_dev_upload(ctx, at(coset(halo_of[a]), 4 * m), nxt[4 * a].l, 128));
+  }
+  pm_plonk_quotient_args qa;
+  memset(&qa, 0, sizeof qa);
+  for (int j = 0; j < 4; ++j) {
+    qa.wires[j] = coset(j);
+    qa.sigmas[j] = at(pk->sigma_coset, 4 * m * j);
+  }
+  qa.z = coset(4);
+  qa.pi = coset(5);
+  qa.q_m = pk->sel_coset[Q_M];
+  qa.q_l = pk->sel_coset[Q_L];
+  qa.q_r = pk->sel_coset[Q_R];
+  qa.q_o = pk->sel_coset[Q_O];
+  qa.q_c = pk->sel_coset[Q_C];
+  qa.q_4 = pk->sel_coset[Q_4];
+  qa.q_arith = pk->sel_coset[Q_ARITH];
+  qa.q_range = pk->sel_coset[Q_RANGE];
+  qa.q_logic = pk->sel_coset[Q_LOGIC];
+  qa.q_fixed_group_add = pk->sel_coset[Q_FIXED];
+  qa.q_variable_group_add = pk->sel_coset[Q_VAR];
+  qa.l1 = pk->l1_coset;
+  qa.x = pk->x4;
+  put(qa.alpha, alpha);
+  put(qa.beta, beta);
+  put(qa.gamma, gamma);
+  put(qa.range_sep, range_sep);
+  put(qa.logic_sep, logic_sep);
+  put(qa.fixed_sep, fixed_sep);
+  put(qa.var_sep, var_sep);
+  for (int j = 0; j < 3; ++j) put(qa.k[j], pk->k[j]);
+  for (int j = 0; j < 4; ++j) put(qa.zh_inv[j], pk->zh_inv[j]);
+  PK_TRY(pm::plonk_quotient_rows(ctx, &qa, m, true, pk->tq, nullptr));
+  {
+    // t's coefficients from its values on the four sub-cosets: D_s = iNTT_n(t on g_s H), D'_s[i] = D_s[i] g_s^-i
+    //   = sum_m' (c_{i + m' n} g^(n m')) i4^(s m'):  a 4-point DFT over m' for every i, undone pointwise
+    for (int s = 0; s < 4; ++s) {
+      void* ds = at(pk->tmp, s * m);
+      PK_TRY(deinterleave(ctx, ds, pk->tq, s, m));
+      PK_TRY(dist_ntt(ctx, D, pk, ds, PM_NTT_INVERSE));
+      PK_TRY(pm_fr_vec_op_dev(ctx, 2, ds, at(pk->gs_inv_pow, s * m), m, ds, m, nullptr));
+    }
+    const HFr i4 = fpow(fmul(pk->gs[1], finv(pk->gs[0])), n), i4_inv = finv(i4);   // w4^n: a primitive fourth root of unity
+    const HFr gn_inv = finv(fpow(pk->gs[0], n)), quarter = finv(fr_u64(4));
+    HFr gm = one;   // g^(-n m')
+    for (int mp = 0; mp < 4; ++mp) {
+      const void* v[4];
+      u64 c[4][4];
+      for (int s = 0; s < 4; ++s) {
+        v[s] = at(pk->tmp, s * m);
+        put(c[s], fmul(fmul(quarter, gm), fpow64(i4_inv, (u64)(s * mp))));
+      }
+      PK_TRY(pm_fr_lincomb_dev(ctx, 4, v, &c[0][0], m, at(pk->t, mp * m), nullptr));
+      gm = fmul(gm, gn_inv);
+    }
+  }
+  PK_TRY(commit_batch_dist(ctx, D, pk, ck, pk->t, n, 4, &out->commitments[5]));
+  for (int i = 0; i < 4; ++i) ts.append_commitment(tl::QUOTIENT[i], out->commitments[5 + i]);
+  // ---- round 4 --------------------------------------------------------------------------------
+  const HFr zc = ts.challenge_scalar(tl::Z_CHALLENGE), zw = fmul(zc, pk->omega);
+  enum { E_A, E_B, E_C, E_D, E_AN, E_BN, E_DN, E_S1, E_S2, E_S3, E_QARITH, E_QC, E_QL, E_QR, E_ZN, E_T, E_R, NEV };
+  HFr ev[NEV];
+  const HFr zc_lo = fpow64(zc, lo), zw_lo = fpow64(zw, lo);
+  {
+    // openings: every rank evaluates its coefficient slice (sum_i c_{lo + i} z^i), scales by z^lo, and the sums go round
+    const void* at_z[15];
+    u64 out_z[15][4], out_zw[4][4];
+    for (int j = 0; j < 4; ++j) at_z[j] = at(pk->coeffs, j * m);
+    for (int j = 0; j < 3; ++j) at_z[4 + j] = at(pk->sigma_coeffs, j * m);
+    at_z[7] = at(pk->sel_coeffs, Q_ARITH * m);
+    at_z[8] = at(pk->sel_coeffs, Q_C * m);
+    at_z[9] = at(pk->sel_coeffs, Q_L * m);
+    at_z[10] = at(pk->sel_coeffs, Q_R * m);
+    for (int i = 0; i < 4; ++i) at_z[11 + i] = at(pk->t, i * m);
+    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 15, at_z, m, zc.l, &out_z[0][0], nullptr));
+    const void* at_zw[4] = {at(pk->coeffs, 0), at(pk->coeffs, m), at(pk->coeffs, 3 * m), z_coeffs};
+    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 4, at_zw, m, zw.l, &out_zw[0][0], nullptr));
+    HFr part[19];
+    for (int j = 0; j < 15; ++j) part[j] = fmul(get(out_z[j]), zc_lo);
+    for (int j = 0; j < 4; ++j) part[15 + j] = fmul(get(out_zw[j]), zw_lo);
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, part, 19, all));
+    HFr sum[19];
+    for (int j = 0; j < 19; ++j) {
+      sum[j] = pm::host::zero<4>();
+      for (uint32_t r = 0; r < W; ++r) sum[j] = fadd(sum[j], all[(size_t)r * 19 + j]);
+    }
+    for (int j = 0; j < 4; ++j) ev[E_A + j] = sum[j];
+    for (int j = 0; j < 3; ++j) ev[E_S1 + j] = sum[4 + j];
+    ev[E_QARITH] = sum[7];
+    ev[E_QC] = sum[8];
+    ev[E_QL] = sum[9];
+    ev[E_QR] = sum[10];
+    ev[E_AN] = sum[15];
+    ev[E_BN] = sum[16];
+    ev[E_DN] = sum[17];
+    ev[E_ZN] = sum[18];
+    const HFr zn_ = fpow(zc, n);
+    ev[E_T] = fadd(sum[11], fmul(zn_, fadd(sum[12], fmul(zn_, fadd(sum[13], fmul(zn_, sum[14]))))));
+  }
+  const HFr zn = fpow(zc, n);
+  const HFr &a_ = ev[E_A], &b_ = ev[E_B], &c_ = ev[E_C], &d_ = ev[E_D], &s1 = ev[E_S1], &s2 = ev[E_S2], &s3 = ev[E_S3],
+            &z_next = ev[E_ZN], &qar = ev[E_QARITH];
+  const HFr l1_z = fmul(fsub(zn, one), finv(fmul(fr_u64(n), fsub(zc, one))));
+  const HFr bz = fmul(beta, zc);
+  HFr ident = fadd(fadd(a_, bz), gamma);
+  const HFr* wv[3] = {&b_, &c_, &d_};
+  for (int j = 0; j < 3; ++j) ident = fmul(ident, fadd(fadd(*wv[j], fmul(bz, pk->k[j])), gamma));
+  const HFr copy3 = fmul(fmul(fadd(fadd(a_, fmul(beta, s1)), gamma), fadd(fadd(b_, fmul(beta, s2)), gamma)),
+                         fadd(fadd(c_, fmul(beta, s3)), gamma));
+  const HFr alpha2 = fmul(alpha, alpha);
+  RowEvals re{a_, b_, c_, d_, ev[E_AN], ev[E_BN], ev[E_DN], ev[E_QL], ev[E_QR], ev[E_QC]};
+  {
+    const void* lin_v[12];
+    u64 lin_c[12][4];
+    uint32_t k = 0;
+    auto term = [&](const void* v, const HFr& c) {
+      lin_v[k] = v;
+      put(lin_c[k], c);
+      ++k;
+    };
+    term(at(pk->sel_coeffs, Q_M * m), fmul(qar, fmul(a_, b_)));
+    term(at(pk->sel_coeffs, Q_L * m), fmul(qar, a_));
+    term(at(pk->sel_coeffs, Q_R * m), fmul(qar, b_));
+    term(at(pk->sel_coeffs, Q_O * m), fmul(qar, c_));
+    term(at(pk->sel_coeffs, Q_4 * m), fmul(qar, d_));
+    term(at(pk->sel_coeffs, Q_C * m), qar);
+    if (!pk->sel_zero[Q_RANGE]) term(at(pk->sel_coeffs, Q_RANGE * m), widget_range(range_sep, re));
+    if (!pk->sel_zero[Q_LOGIC]) term(at(pk->sel_coeffs, Q_LOGIC * m), widget_logic(logic_sep, re));
+    if (!pk->sel_zero[Q_FIXED]) term(at(pk->sel_coeffs, Q_FIXED * m), widget_fixed(fixed_sep, re));
+    if (!pk->sel_zero[Q_VAR]) term(at(pk->sel_coeffs, Q_VAR * m), widget_var(var_sep, re));
+    term(z_coeffs, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)));
+    term(at(pk->sigma_coeffs, 3 * m), fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next)));
+    PK_TRY(pm_fr_lincomb_dev(ctx, k, lin_v, &lin_c[0][0], m, pk->r, nullptr));
+  }
+  {
+    HFr part;
+    PK_TRY(pm_fr_poly_evaluate_dev(ctx, pk->r, m, zc.l, part.l, nullptr));
+    part = fmul(part, zc_lo);
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, &part, 1, all));
+    ev[E_R] = pm::host::zero<4>();
+    for (uint32_t r = 0; r < W; ++r) ev[E_R] = fadd(ev[E_R], all[r]);
+  }
+  static_assert(NEV == 17, "tl::EVALS lists the evaluations in this enum's order");
+  for (int i = 0; i < NEV; ++i) {
+    ts.append_scalar(tl::EVALS[i], ev[i]);
+    put(out->evaluations[i], ev[i]);
+  }
+  // ---- round 5 --------------------------------------------------------------------------------
+  const HFr aw = ts.challenge_scalar(tl::AGGREGATE);
+  const HFr aws = ts.challenge_scalar(tl::AGGREGATE);
+  void *agg1 = pk->agg, *agg2 = at(pk->agg, m);
+  {
+    const void* agg_v[12];
+    u64 agg_c[12][4];
+    HFr ac[12];
+    ac[0] = one;
+    ac[1] = zn;
+    ac[2] = fmul(zn, zn);
+    ac[3] = fmul(ac[2], zn);
+    HFr vp = one;
+    for (int e = 0; e < 8; ++e) {
+      vp = fmul(vp, aw);
+      ac[4 + e] = vp;
+    }
+    for (int i = 0; i < 4; ++i) agg_v[i] = at(pk->t, i * m);
+    agg_v[4] = pk->r;
+    for (int j = 0; j < 4; ++j) agg_v[5 + j] = at(pk->coeffs, j * m);
+    for (int j = 0; j < 3; ++j) agg_v[9 + j] = at(pk->sigma_coeffs, j * m);
+    for (int i = 0; i < 12; ++i) put(agg_c[i], ac[i]);
+    PK_TRY(pm_fr_lincomb_dev(ctx, 12, agg_v, &agg_c[0][0], m, agg1, nullptr));
+    const void* sh_v[4] = {z_coeffs, at(pk->coeffs, 0), at(pk->coeffs, m), at(pk->coeffs, 3 * m)};
+    u64 sh_c[4][4];
+    vp = one;
+    for (int e = 0; e < 4; ++e) {
+      put(sh_c[e], vp);
+      vp = fmul(vp, aws);
+    }
+    PK_TRY(pm_fr_lincomb_dev(ctx, 4, sh_v, &sh_c[0][0], m, agg2, nullptr));
+  }
+  {
+    // Ruffini over the ranks: q_k = sum_{j > k} c_j z^(j - k - 1).  The part with j inside the slice is the slice's own
+    // division; the part above it is  z^(hi - 1 - k) H,  H = sum over the ranks above of (z^m)^(r' - r - 1) P_r',
+    // P_r' = that rank's slice evaluated at z (sum_i c_{lo' + i} z^i): one exchange of two scalars.
+    HFr P[2];
+    PK_TRY(pm_fr_poly_evaluate_dev(ctx, agg1, m, zc.l, P[0].l, nullptr));
+    PK_TRY(pm_fr_poly_evaluate_dev(ctx, agg2, m, zw.l, P[1].l, nullptr));
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, P, 2, all));
+    const HFr pts[2] = {zc, zw};
+    const void* src[2] = {agg1, agg2};
+    for (int q = 0; q < 2; ++q) {
+      void* dst = at(pk->wit, q * m);
+      PK_TRY(pm_fr_poly_ruffini_dev(ctx, src[q], m, pts[q].l, dst, nullptr));   // m - 1 coefficients
+      PM_HIP(ctx, hipMemsetAsync(at(dst, m - 1), 0, 32, st));
+      const HFr zm = fpow64(pts[q], m);
+      HFr H = pm::host::zero<4>();
+      for (uint32_t r = W; r-- > rk + 1;) H = fadd(fmul(H, zm), all[(size_t)r * 2 + q]);
+      const HFr zi = finv(pts[q]);
+      PK_TRY(pm_fr_powers_dev(ctx, zi.l, fmul(H, fpow64(pts[q], m - 1)).l, m, pk->tmp, nullptr));   // H z^(m - 1 - i)
+      PK_TRY(pm_fr_vec_op_dev(ctx, 0, dst, pk->tmp, m, dst, m, nullptr));
+    }
+  }
+  PK_TRY(commit_batch_dist(ctx, D, pk, ck, pk->wit, n - 1, 2, &out->commitments[9]));
+  ts.append_commitment(tl::W_Z, out->commitments[9]);
+  ts.append_commitment(tl::W_ZW, out->commitments[10]);
+  const HFr chal[10] = {beta, gamma, alpha, range_sep, logic_sep, fixed_sep, var_sep, zc, aw, aws};
+  for (int i = 0; i < 10; ++i) put(out->challenges[i], chal[i]);
+  return PM_OK;
+}
+
+extern "C" int pm_plonk_prove_dist(pm_ctx* ctx, const pm_dist* dist, pm_dist_key* key, const pm_bases* ck_slice,
+                                   const void* d_witness_slices, const uint64_t* pi_positions, const uint64_t* pi_values,
+                                   size_t n_pi, uint32_t flags, pm_plonk_proof* out) {
+  if (!ctx || !dist) return PM_ERR_BAD_ARG;
+  Dist D;
+  D.d = *dist;
+  D.expect = 10;
+  return dist_leave(ctx, D, prove_dist_body(ctx, D, key, ck_slice, d_witness_slices, pi_positions, pi_values, n_pi, flags, out));
+}

@@ -10,6 +10,8 @@ nothing is exchanged.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from .host import Bases, Context, Error, g1_fold, g1_to_affine
@@ -110,6 +112,7 @@ class LocalGroup:
         self._barrier = threading.Barrier(world, timeout=timeout)
         self._msgs = np.zeros((world, 1 + 18 * _MAX_PARTIALS), np.uint64)
         self._send = [None] * world
+        self._words = np.zeros((world, _lib.COMM_MSG_WORDS), np.uint64)
 
     def allgather_fold_many(self, rank: int, partials_xyz):
         """``allgather_fold_many`` among the threads of the group (``partials_xyz=None`` = abort marker)."""
@@ -120,6 +123,26 @@ class LocalGroup:
         stacked = self._msgs.copy()
         self._barrier.wait()                       # every rank has its copy: the slots may be overwritten
         return _fold_messages(stacked, partials_xyz is None, p)
+
+    def allgather_words(self, rank: int, words: np.ndarray) -> np.ndarray:
+        """One fixed-size message per rank -> [world, words] on every rank (the distributed prover's all-gather)."""
+        self._words[rank] = words
+        self._barrier.wait()
+        out = self._words.copy()
+        self._barrier.wait()
+        return out
+
+    def alltoall_tensors(self, rank: int, send, recv) -> int:
+        """Block p of `recv` <- block `rank` of rank p's `send` (device tensors of equal size on every rank)."""
+        import torch
+        per = send.shape[0] // self.world
+        self._send[rank] = send
+        self._barrier.wait()
+        for p_, s in enumerate(list(self._send)):
+            recv[p_ * per:(p_ + 1) * per].copy_(s[rank * per:(rank + 1) * per])
+        torch.cuda.synchronize()
+        self._barrier.wait()                       # the peers have read this rank's send buffer
+        return 0
 
     def alltoall_fn(self, rank: int, stage):
         """ALLTOALL_FN for ``pm_fr_ntt_fourstep_dev``: ``stage`` is this rank's [2 blk, 4] tensor (send | recv);
@@ -146,6 +169,80 @@ class LocalGroup:
             except Exception:                      # never raise through the C frame (a broken barrier included)
                 return 1
         return _lib.ALLTOALL_FN(cb)
+
+
+class _DevPtr:
+    """A raw device pointer as a ``__cuda_array_interface__`` object: ``torch.as_tensor`` wraps it without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def _dev_tensor(ptr: int, nbytes: int, device):
+    import torch
+    return torch.as_tensor(_DevPtr(ptr, nbytes), device=device)
+
+
+class DistGroup:
+    """The two exchange callbacks of the distributed prover (``pm_plonk_*_dist``: coefficient-range ownership end to
+    end) over one of two transports: the default ``torch.distributed`` process group (one
+    process per rank; gloo rehearsals move the bytes through the host) or a :class:`LocalGroup` (ranks = threads of this
+    process).  ``desc`` is the ``pm_dist`` to pass; with ``native=True`` both callbacks are NULL and the library uses
+    its own RCCL communicator (``Context.comm_init`` first)."""
+
+    def __init__(self, rank: int | None = None, world: int | None = None, local: "LocalGroup | None" = None,
+                 device="cuda", native: bool = False):
+        import torch.distributed as tdist
+        self.local, self.device = local, device
+        if local is not None:
+            self.world, self.rank = local.world, int(rank)
+        else:
+            self.world = tdist.get_world_size() if tdist.is_initialized() else 1
+            self.rank = tdist.get_rank() if tdist.is_initialized() else 0
+        self._ag = None if native else _lib.ALLGATHER_FN(self._allgather)
+        self._aa = None if native else _lib.ALLTOALL_FN(self._alltoall)
+        self.desc = _lib.Dist(self.world, self.rank, C.cast(self._ag, C.c_void_p) if self._ag else None,
+                              C.cast(self._aa, C.c_void_p) if self._aa else None, None)
+
+    def _allgather(self, _user, msg, gathered):
+        try:
+            words = _lib.COMM_MSG_WORDS
+            mine = np.ctypeslib.as_array(msg, shape=(words,)).copy()
+            out = np.ctypeslib.as_array(gathered, shape=(self.world, words))
+            if self.local is not None:
+                out[:] = self.local.allgather_words(self.rank, mine)
+            elif self.world == 1:
+                out[0] = mine
+            else:
+                import torch
+                import torch.distributed as tdist
+                t = torch.from_numpy(mine.view(np.int64))
+                dev = self.device if tdist.get_backend() == "nccl" else "cpu"
+                parts = [torch.empty_like(t, device=dev) for _ in range(self.world)]
+                tdist.all_gather(parts, t.to(dev))
+                out[:] = torch.stack(parts).cpu().numpy().view(np.uint64)
+            return 0
+        except Exception:            # never unwind through the C frames
+            return 1
+
+    def _alltoall(self, _user, d_send, d_recv, bytes_per_peer):
+        try:
+            import torch
+            nbytes = bytes_per_peer * self.world
+            send, recv = _dev_tensor(d_send, nbytes, self.device), _dev_tensor(d_recv, nbytes, self.device)
+            if self.local is not None:
+                return self.local.alltoall_tensors(self.rank, send, recv)
+            import torch.distributed as tdist
+            if tdist.get_backend() != "nccl":                     # gloo rehearsal: exchange on the host
+                s, r = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+                tdist.all_to_all_single(r, s)
+                recv.copy_(r)
+            else:
+                tdist.all_to_all_single(recv, send)
+            torch.cuda.synchronize()
+            return 0
+        except Exception:
+            return 1
 
 
 class ShardedCommitKey:

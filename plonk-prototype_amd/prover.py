@@ -167,6 +167,98 @@ class ProverKey:
             pass
 
 
+class DistProverKey:
+    """``pm_dist_key``: this rank's share of a prover key with coefficient-range ownership end to end (rows /
+    coefficients [rank n / world, (rank + 1) n / world) of every vector; SURVEY.md section 8f N5, configs[4]).
+    ``circuit`` is the WHOLE circuit here (the slices are cut from it; a host that never holds the whole circuit
+    passes slices to ``pm_plonk_preprocess_dist`` directly); ``group`` a ``dist.DistGroup``."""
+
+    def __init__(self, circuit: Circuit, ctx: Context, group):
+        self.ctx, self.n, self.group = ctx, circuit.n, group
+        W, r = group.world, group.rank
+        if self.n % W:
+            raise ValueError("the ranks must divide the circuit size")
+        m = self.n // W
+        self.m, self.lo = m, r * m
+        keep = []
+        ptrs = (_lib.u64p * len(SELECTORS))()
+        for i, s in enumerate(SELECTORS):
+            a = getattr(circuit, s)
+            if a is not None:
+                a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64).reshape(-1, 4)[self.lo:self.lo + m])
+                keep.append(a)
+                ptrs[i] = a.ctypes.data_as(_lib.u64p)
+        idx = np.ascontiguousarray(np.asarray(circuit.sigma_index, dtype=np.int64).reshape(4, self.n)[:, self.lo:self.lo + m])
+        h = C.c_void_p()
+        ctx._check(ctx._lib.pm_plonk_preprocess_dist(ctx._h, C.byref(group.desc), ptrs, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     self.n, C.byref(h)))
+        self._h = h
+        self.verifier_key: dict | None = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.ctx._lib.pm_plonk_dist_key_bytes(self._h))
+
+    def commit(self, bases_slice, label: bytes = b"plonk") -> dict:
+        """bases_slice: ``host.Bases`` holding powers [rank m, (rank + 1) m) of the commit key."""
+        vk = _lib.VK_POINTS()
+        self.ctx._check(self.ctx._lib.pm_plonk_key_commit_dist(self.ctx._h, C.byref(self.group.desc), self._h, bases_slice._h,
+                                                               label, C.byref(vk)))
+        self.verifier_key = {nm: np.array(vk[i], dtype=np.uint64) for i, nm in enumerate(VK_NAMES)}
+        return self.verifier_key
+
+    def prove(self, bases_slice, witness, public_inputs=None, bind_public_inputs: bool = True) -> "Proof":
+        """witness: the WHOLE [4, n, 4] wire values (this rank uploads its [4, m] slices) or a DeviceVector of this
+        rank's 4m elements; public inputs as for ``prove`` (global positions)."""
+        ctx, m = self.ctx, self.m
+        if isinstance(witness, DeviceVector):
+            d_wit, own = witness, False
+        else:
+            w = np.asarray(witness, dtype=np.uint64).reshape(4, self.n, 4)[:, self.lo:self.lo + m]
+            d_wit, own = DeviceVector.from_host(ctx, np.ascontiguousarray(w).reshape(4 * m, 4)), True
+        if isinstance(public_inputs, tuple):
+            pos = np.ascontiguousarray(public_inputs[0], dtype=np.uint64).reshape(-1)
+            val = np.ascontiguousarray(public_inputs[1], dtype=np.uint64).reshape(-1, 4)
+        else:
+            pos, val = sparse_public_inputs(public_inputs)
+        raw = _lib.PlonkProof()
+        flags = 0 if bind_public_inputs else _lib.PLONK_UPSTREAM_TRANSCRIPT
+        try:
+            ctx._check(ctx._lib.pm_plonk_prove_dist(ctx._h, C.byref(self.group.desc), self._h, bases_slice._h, d_wit._p,
+                                                    pos.ctypes.data_as(_lib.u64p) if pos.size else None,
+                                                    val.ctypes.data_as(_lib.u64p) if pos.size else None, pos.size, flags,
+                                                    C.byref(raw)))
+        finally:
+            if own:
+                d_wit.free()
+        return _proof_from_raw(ctx, raw)
+
+    def free(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            self.ctx._lib.pm_plonk_dist_key_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _proof_from_raw(ctx: Context, raw) -> "Proof":
+    proof = Proof()
+    for i, name in enumerate(Proof.COMMITMENTS):
+        proof.commitments[name] = np.array(raw.commitments[i], dtype=np.uint64)
+    for i, name in enumerate(Proof.TRANSCRIPT_EVALS):
+        proof.evaluations[name] = np.array(raw.evaluations[i], dtype=np.uint64)
+    for i, name in enumerate(CHALLENGES):
+        proof.challenges[name] = fr_from_limbs(np.array(raw.challenges[i], dtype=np.uint64))
+    buf = (C.c_uint8 * _lib.PLONK_PROOF_BYTES)()
+    ctx._check(ctx._lib.pm_plonk_proof_to_bytes(C.byref(raw), buf))
+    proof.native_bytes = bytes(buf)
+    return proof
+
+
 def preprocess(circuit: Circuit, ctx: Context, ck=None, label: bytes = b"plonk") -> ProverKey:
     """``Prover::preprocess``.  With a commit key the verifier key is committed and the transcript seeded
     right away; otherwise ``prove`` does it with its commit key before the first proof."""
@@ -249,17 +341,7 @@ def prove(pk: ProverKey, ck: CommitKey, witness, public_inputs=None, bind_public
     finally:
         if own:
             d_wit.free()
-    proof = Proof()
-    for i, name in enumerate(Proof.COMMITMENTS):
-        proof.commitments[name] = np.array(raw.commitments[i], dtype=np.uint64)
-    for i, name in enumerate(Proof.TRANSCRIPT_EVALS):
-        proof.evaluations[name] = np.array(raw.evaluations[i], dtype=np.uint64)
-    for i, name in enumerate(CHALLENGES):
-        proof.challenges[name] = fr_from_limbs(np.array(raw.challenges[i], dtype=np.uint64))
-    buf = (C.c_uint8 * _lib.PLONK_PROOF_BYTES)()
-    ctx._check(ctx._lib.pm_plonk_proof_to_bytes(C.byref(raw), buf))
-    proof.native_bytes = bytes(buf)
-    return proof
+    return _proof_from_raw(ctx, raw)
 
 
 def seeded_transcript(verifier_key: dict, n: int, label: bytes | None = None) -> Transcript:

@@ -1,0 +1,177 @@
+"""The prover with coefficient-range ownership end to end (pm_plonk_*_dist; SURVEY.md section 8e row 3 + 8f N5, VERDICT
+r03 #5): rank r of W holds rows / coefficients [r n / W, (r + 1) n / W) of every vector, the size-n transforms run as
+the four-step transform over the ranks, and NOTHING is replicated -- yet the proof and the verifier key must equal the
+single-GPU prover's byte for byte on every rank.  Ranks are threads of this process (dist.LocalGroup, as in
+tests/test_gpu_world8.py) and, once, spawned gloo processes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_gpu_world8 import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(proof, vk):
+    return proof.to_bytes() + b"".join(vk[k].tobytes() for k in sorted(vk))
+
+
+def _inputs(n, mixed, seed):
+    import plonk_prototype_amd as pa
+    from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+    circuit, wit, pi = (pa.synthetic.mixed_circuit if mixed else pa.synthetic.chain_circuit)(n, seed)
+    srs = CpuOracle().g1_bases_arith(ints_to_limbs([77], 4)[0], ints_to_limbs([0x10001], 4)[0], n, 4)
+    return circuit, wit, pi, srs
+
+
+@pytest.mark.parametrize("log_n,world,mixed", [(12, 2, True), (12, 4, False), (14, 4, True), (16, 2, False), (16, 4, True),
+                                               (8, 4, True), (6, 8, False)])
+def test_dist_prover_equals_single_gpu(ctx, log_n, world, mixed):
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    n = 1 << log_n
+    circuit, wit, pi, srs = _inputs(n, mixed, 31 + log_n)
+    ck = pa.CommitKey(srs, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
+    single = _blob(PR.prove(pk, ck, wit, pi), pk.verifier_key)
+    upstream = PR.prove(pk, ck, wit, pi, bind_public_inputs=False).to_bytes()
+    full_bytes = None
+    m = n // world
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            grp = DistGroup(rank=r, local=g)
+            key = PR.DistProverKey(circuit, c, grp)
+            bases = pa.host.Bases(c, srs[r * m:(r + 1) * m])
+            if r & 1:
+                bases.precompute()                      # table and no table side by side
+            key.commit(bases)
+            out = _blob(key.prove(bases, wit, pi), key.verifier_key)
+            again = key.prove(bases, wit, pi, bind_public_inputs=False).to_bytes()
+            nbytes = key.device_bytes
+            key.free()
+            return out, again, nbytes
+        finally:
+            c.close()
+    for r, (out, again, nbytes) in enumerate(run_ranks(world, body)):
+        assert out == single, r
+        assert again == upstream, r
+        # per-rank memory: what a rank holds is 1 / world of the single-GPU key's arrays (plus halos and a scalar)
+        assert nbytes <= (160 * n // world + 6 * 4 + 1) * 32, (r, nbytes)
+
+
+def test_dist_prover_failure_does_not_block(ctx):
+    """A public input outside the circuit on ONE rank: that rank gets PM_ERR_LENGTH, its peers PM_ERR_EXCHANGE from their
+    next all-gather, nobody blocks, and the keys prove normally afterwards; a short commit-key slice likewise."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    n, world = 1 << 10, 4
+    circuit, wit, pi, srs = _inputs(n, True, 5)
+    m = n // world
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            grp = DistGroup(rank=r, local=g)
+            key = PR.DistProverKey(circuit, c, grp)
+            bases = pa.host.Bases(c, srs[r * m:(r + 1) * m])
+            short = pa.host.Bases(c, srs[r * m:(r + 1) * m - (1 if r == 2 else 0)])
+            codes = []
+            try:
+                key.commit(short)
+                codes.append(0)
+            except pa.Error as e:
+                codes.append(e.code)
+            key.commit(bases)
+            pos, val = PR.sparse_public_inputs(pi)
+            bad = pos.copy()
+            if r == 1:
+                bad[0] = n + 3
+            try:
+                key.prove(bases, wit, (bad, val))
+                codes.append(0)
+            except pa.Error as e:
+                codes.append(e.code)
+            codes.append(len(key.prove(bases, wit, pi).to_bytes()))
+            key.free()
+            return codes
+        finally:
+            c.close()
+    res = run_ranks(world, body)
+    for r, codes in enumerate(res):
+        assert codes == [-6 if r == 2 else -7, -6 if r == 1 else -7, 1040], (r, codes)
+
+
+def test_dist_rejects_bad_groups(ctx):
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup, LocalGroup
+    circuit, wit, pi, srs = _inputs(16, False, 1)
+    for world in (3, 8):                      # not a power of two; world^2 > n
+        grp = DistGroup(rank=0, local=LocalGroup(world))
+        with pytest.raises((pa.Error, ValueError)):
+            PR.DistProverKey(circuit, ctx, grp)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1 << 12
+        circuit, wit, pi, srs = _inputs(n, True, 77)
+        c = pa.Context(0)
+        grp = DistGroup()                      # the default process group
+        key = PR.DistProverKey(circuit, c, grp)
+        m = n // world
+        bases = pa.host.Bases(c, srs[rank * m:(rank + 1) * m])
+        key.commit(bases)
+        q.put((rank, list(_blob(key.prove(bases, wit, pi), key.verifier_key))))
+        key.free()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_prover_over_gloo_processes(ctx):
+    """One process per rank (how a node runs it), gloo carrying both exchanges through the host."""
+    import torch.multiprocessing as mp
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    n = 1 << 12
+    circuit, wit, pi, srs = _inputs(n, True, 77)
+    ck = pa.CommitKey(srs, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
+    single = list(_blob(PR.prove(pk, ck, wit, pi), pk.verifier_key))
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, blob in res:
+        assert blob == single, rank
