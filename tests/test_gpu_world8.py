@@ -243,3 +243,45 @@ def test_four_step_ntt_world8(ctx, oracle, log_ns):
         finally:
             c.close()
     assert run_ranks(world, body) == [[]] * world
+
+
+def test_dist_prover_world8_at_2_20_gates(ctx, oracle):
+    """configs[4]'s world size with NOTHING replicated (pm_plonk_*_dist): 8 ranks, 2^20 gates, every rank
+    holding 2^17 rows / coefficients of every vector and a 2^17-point slice of the commit key -- proof and verifier key
+    byte-equal to the single-context ones, and each rank's device memory an eighth of a single-GPU key's."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup, ShardedCommitKey
+    from test_gpu_prover import TAU, _mont
+    gk, world = 20, 8
+    n = 1 << gk
+    m = n // world
+    circuit, d_wit, _ = pa.synthetic.wide_circuit(n, ctx, seed=5)
+    wit = d_wit.to_host()
+    ck = pa.CommitKey.setup(n - 1, _mont(oracle, TAU), ctx, precompute=True)
+    pk = PR.preprocess(circuit, ctx, ck)
+    single = _blob(PR.prove(pk, ck, d_wit, None), pk)
+    pk.free()
+    ck._bases.free()
+    d_wit.free()
+    ctx.trim()
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            grp = DistGroup(rank=r, local=g)
+            bases = ShardedCommitKey.setup(n, TAU, r * m, (r + 1) * m, c, group=g, rank=r, precompute=bool(r & 1))._bases
+            key = PR.DistProverKey(circuit, c, grp)
+            key.commit(bases)
+            proof = key.prove(bases, wit.reshape(4, n, 4), None)
+            out = proof.to_bytes() + b"".join(key.verifier_key[k].tobytes() for k in sorted(key.verifier_key))
+            nbytes = key.device_bytes
+            key.free()
+            return out, nbytes
+        finally:
+            c.close()
+    res = run_ranks(world, body)
+    for r, (out, nbytes) in enumerate(res):
+        assert out == single, r
+        assert nbytes <= 161 * m * 32, (r, nbytes)       # ~0.67 GB per rank at 2^20 gates on 8 ranks
+    print(f"[n5] 2^20 gates on 8 ranks: {res[0][1] / 2**20:.0f} MiB of key + workspace per rank")
