@@ -75,6 +75,8 @@ def main():
                     help="gates of the synthetic circuit for the full-prove entry (BASELINE configs[3])")
     ap.add_argument("--cpu-prover-log-n", type=int, default=20,
                     help="gates of the CPU-baseline proof (2^18: ~8 s on 16 threads; 2^20, the GPU leg's size: ~35 s)")
+    ap.add_argument("--leg-timeout", type=int, default=420,
+                    help="N > 1: seconds the sharded MSM / prover legs may take before the watchdog prints the line without them")
     ap.add_argument("--fourstep-log-n", type=int, default=0,
                     help="N > 1 only, off by default: also time ONE 2^K transform split over the ranks "
                          "(pm_fr_ntt_fourstep_dev, SURVEY 8f N5) through the library's RCCL communicator")
@@ -149,7 +151,11 @@ def main():
         print(f"[bench] rank {rank}/{world} device {local_rank}: library communicator "
               f"{'rank %d of %d' % (_r.value, _w.value) if native_comm else 'NOT in use (torch.distributed ' + backend + ')'}",
               file=sys.stderr, flush=True)
-    stream = torch.cuda.current_stream().cuda_stream
+    # The launches go to the context's OWN stream (stream = 0 in the calls below: the null handle means that; a foreign
+    # stream costs one ordering event per call, +2 % on the headline step).  The timing events must be recorded on that
+    # same stream -- torch's default stream would bracket nothing -- so it is wrapped for torch (pm_ctx_stream).
+    tstream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+    stream = 0
     # host threads we may use: the box's CPU share, not every core the kernel lists
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
 
@@ -184,10 +190,10 @@ def main():
     for r_ in range(repeats):
         barrier()
         t0 = time.perf_counter()
-        ev[r_][0].record()
+        ev[r_][0].record(tstream)
         for _ in range(args.steps):
             step()
-        ev[r_][1].record()
+        ev[r_][1].record(tstream)
         barrier()
         host_dts.append(time.perf_counter() - t0)
     dev_dts = [a_.elapsed_time(b_) * 1e-3 for a_, b_ in ev]
@@ -247,6 +253,43 @@ def main():
                                f"pair around every kernel); `value` is from the loop with the timers off",
                 "pmc_evidence": "profiles/r04_pmc_summary.json (offline rocprofv3 --pmc passes of this command)",
                 "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
+
+    # ------------------------------------------------------------------ the one JSON line, and a safety net for N > 1
+    # The headline above needs no data-path collective; the legs below do when N > 1 (the sharded MSM and prover through
+    # RCCL).  `legs` collects what has finished; with N > 1 a watchdog prints the line with what there is and ends the
+    # process if the remaining legs do not finish in time (a collective that never returns has no other way out), so the
+    # driver always gets its line.
+    legs = {}
+
+    def emit_line(note=None):
+        out = {"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": value, "unit": "butterflies/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "timing": timing,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, Fr)",
+               "data": "synthetic",
+               "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "
+                                      f"natural order in/out, bit-exact vs oracle", "log_n": k, "passes": passes,
+                          "parallelism": f"{world} independent polynomial(s), one per GPU"},
+               "exchange": (None if world == 1 else "library RCCL communicator (pm_comm_init / pm_g1_allgather_fold)"
+                            if native_comm else f"torch.distributed ({backend})"),
+               "roofline": roofline, "cpu_baseline": legs.get("cpu"), "ntt_extra": legs.get("ntt_extra"),
+               "ntt_fourstep": legs.get("fourstep"), "msm": legs.get("msm"), "msm_large": legs.get("msm_large"),
+               "next_rows": legs.get("poly"), "prover": legs.get("prover")}
+        if note:
+            out["note"] = note
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    import threading
+    legs_done = threading.Event()
+    if world > 1:
+        def watchdog():
+            if not legs_done.wait(args.leg_timeout):
+                if rank == 0:
+                    emit_line(f"the multi-GPU legs did not finish within {args.leg_timeout} s (a collective that never "
+                              f"returned?): line printed by the watchdog with the legs that had finished")
+                os._exit(0 if rank == 0 else 3)
+        threading.Thread(target=watchdog, daemon=True).start()
 
     # ------------------------------------------------------------------ NTT extras (rank 0): SURVEY 8d
     ntt_extra = None
@@ -353,6 +396,7 @@ def main():
                                   "butterflies_per_s": (2 * n) * (k + 2) / c4}}
         del d4
 
+    legs.update(ntt_extra=ntt_extra)
     # ------------------------------------------------------------------ MSM legs
     k0, dd = 0x1234567, 0xabcdef123456789abcdef
 
@@ -514,6 +558,7 @@ def main():
         if args.msm_large_log_n > args.msm_log_n:
             msm_large, _, _ = run_msm(args.msm_large_log_n, 2, True)
 
+    legs.update(msm=msm, msm_large=msm_large)
     # ------------------------------------------------------------------ optional: one transform over all ranks (N5)
     fourstep = None
     if world > 1 and args.fourstep_log_n and native_comm:
@@ -590,6 +635,7 @@ def main():
     # ------------------------------------------------------------------ full prove (N1 + N2)
     # N = 1: one GPU proves.  N > 1 (BASELINE configs[4] shape): every rank runs the rounds, the 11 MSMs
     # are split by coefficient range over the ranks' SRS shards, partial points all-gathered and folded.
+    legs.update(fourstep=fourstep, poly=poly)
     prover = None
     if not args.no_prover and msm is not None and args.prover_log_n == args.msm_log_n:
         from plonk_prototype_amd.dist import ShardedCommitKey
@@ -820,6 +866,7 @@ def main():
                                                            f"{cores} threads: outside the bounded-sample budget; pass --cpu-prover-log-n {gk}"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+    legs.update(prover=prover)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -861,21 +908,10 @@ def main():
             cpu["msm_single_thread_value"] = s1n / t1msm
             cpu["msm_single_thread_sample"] = f"one 2^{s1n.bit_length() - 1}-point Pippenger MSM on 1 thread ({t1msm:.1f} s)"
 
+    legs.update(cpu=cpu, ntt_extra=ntt_extra, fourstep=fourstep, msm=msm, msm_large=msm_large, poly=poly, prover=prover)
+    legs_done.set()
     if rank == 0:
-        out = {"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": value, "unit": "butterflies/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "timing": timing,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, Fr)",
-               "data": "synthetic",
-               "config": {"workload": f"forward + inverse BLS12-381 Fr NTT, 2^{k} points, device resident, "
-                                      f"natural order in/out, bit-exact vs oracle", "log_n": k, "passes": passes,
-                          "parallelism": f"{world} independent polynomial(s), one per GPU"},
-               "exchange": (None if world == 1 else "library RCCL communicator (pm_comm_init / pm_g1_allgather_fold)"
-                            if native_comm else f"torch.distributed ({backend})"),
-               "roofline": roofline, "cpu_baseline": cpu, "ntt_extra": ntt_extra, "ntt_fourstep": fourstep, "msm": msm, "msm_large": msm_large, "next_rows": poly,
-               "prover": prover}
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit_line()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -87,6 +87,9 @@ void pm_shutdown(pm_ctx* ctx);
 const char* pm_last_error(const pm_ctx* ctx);
 /* Block until everything queued on the context's stream has finished. */
 int pm_sync(pm_ctx* ctx);
+/* The context's own HIP stream (a hipStream_t; what hip_stream = NULL means in the *_dev entry points): for callers that
+ * order their own work after the library's, or record timing events around it.  Owned by the context. */
+void* pm_ctx_stream(pm_ctx* ctx);
 /* Give back what the context caches between calls -- pass buffers, MSM / polynomial workspaces, staging, twiddle tables --
  * after waiting for the device; everything is rebuilt or regrown on demand (a workspace only ever grows otherwise: after
  * one 2^30-point transform a context holds 77 GB of pass buffers).  pm_bases and pm_prover_key objects are untouched.

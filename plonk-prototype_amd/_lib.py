@@ -62,6 +62,7 @@ SIGNATURES = {
     "pm_shutdown": (None, [C.c_void_p]),
     "pm_last_error": (C.c_char_p, [C.c_void_p]),
     "pm_sync": (C.c_int, [C.c_void_p]),
+    "pm_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "pm_trim": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "pm_domain_info": (C.c_int, [C.c_uint32, u64p, u64p, u64p]),
     "pm_domain_prepare": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -206,6 +206,8 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
 
 extern "C" const char* pm_last_error(const pm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+extern "C" void* pm_ctx_stream(pm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 extern "C" int pm_sync(pm_ctx* ctx) {
   if (!ctx) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

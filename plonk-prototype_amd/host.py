@@ -72,6 +72,11 @@ class Context:
     def sync(self):
         self._check(self._lib.pm_sync(self._h))
 
+    def stream_handle(self) -> int:
+        """``pm_ctx_stream``: the context's own HIP stream (what ``stream = 0`` means in the ``*_dev`` calls), e.g. for
+        ``torch.cuda.ExternalStream`` -- to order other work after the library's or to record timing events on it."""
+        return int(self._lib.pm_ctx_stream(self._h) or 0)
+
     def trim(self) -> int:
         """``pm_trim``: release the cached workspaces and twiddle tables (regrown on demand) -> bytes freed."""
         freed = C.c_size_t(0)

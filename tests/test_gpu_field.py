@@ -41,3 +41,15 @@ def test_inverse(ctx, oracle, field):
     am = to_mont(ints_to_limbs(a, nl))
     got = limbs_to_ints(from_mont(ctx.field_op(op, am, am)))
     assert got == [pow(x, -1, mod) if x else 0 for x in a], field
+
+
+def test_inverse_ignores_b(ctx, oracle):
+    """ops 6 / 7 document `b ignored`: NULL must be accepted; the binary ops still need both operands."""
+    import ctypes as C
+    from plonk_prototype_amd import _lib
+    a = oracle.fr_to_mont(ints_to_limbs([5, 7, 11], 4))
+    out = np.empty_like(a)
+    u64p = _lib.u64p
+    assert ctx._lib.pm_test_field_op(ctx._h, 6, a.ctypes.data_as(u64p), None, out.ctypes.data_as(u64p), 3) == 0
+    assert limbs_to_ints(oracle.fr_from_mont(out)) == [pow(x, -1, B.R_MOD) for x in (5, 7, 11)]
+    assert ctx._lib.pm_test_field_op(ctx._h, 0, a.ctypes.data_as(u64p), None, out.ctypes.data_as(u64p), 3) == _lib.PM_ERR_BAD_ARG

@@ -315,6 +315,21 @@ def test_transcript_modes(ctx, oracle):
     assert PR.prove(pk, ck, wit, (zpos, zval), bind_public_inputs=False).to_bytes() == up.to_bytes()
 
 
+def test_contradicting_transcript_flags_are_rejected(ctx, oracle):
+    """PM_PLONK_BIND_PUBLIC_INPUTS | PM_PLONK_UPSTREAM_TRANSCRIPT name two different transcripts (r03 silently
+    used the upstream one)."""
+    import ctypes as C
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd import _lib
+    circuit, wit, pi, srs, ck, pk, _ = _setup(ctx, oracle, 16, 3)
+    d_wit = pa.DeviceVector.from_host(ctx, np.ascontiguousarray(wit, dtype=np.uint64).reshape(64, 4))
+    raw = _lib.PlonkProof()
+    rc = ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, None, None, 0, 3, C.byref(raw))
+    assert rc == _lib.PM_ERR_BAD_ARG
+    assert ctx._lib.pm_plonk_prove(ctx._h, pk._h, ck._bases._h, d_wit._p, None, None, 0, 1, C.byref(raw)) == 0
+    d_wit.free()
+
+
 def test_several_public_inputs(ctx, oracle):
     """Public inputs on several rows (first, inner, last): the dense PI vector the library builds from the
     (position, value) pairs equals the one the oracle proves with, and each of them moves the challenges."""

@@ -2,7 +2,7 @@
 # One consolidated GPU validation (run through gpurun): tests, bench, smoke, rocprof stats, PMC.
 # Everything is written under gpurun_out/$1/; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,8 +19,8 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smok
 (cd /tmp && export TMPDIR=/tmp && \
  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/bench.py --steps 200 --no-cpu-baseline --no-msm --no-poly --no-prover --no-ntt-extra > $OUT/stats_headline.json 2> $OUT/stats_headline.err && \
  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --no-cpu-baseline --msm-large-log-n 0 --no-poly --no-ntt-extra > $OUT/stats_bench.json 2> $OUT/stats.err && \
- timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm -- python3 $R/tools/msm_table_sweep.py 20 20 8 > $OUT/stats_msm.txt 2> $OUT/stats_msm.err && \
- timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm24 -- python3 $R/tools/msm_table_sweep.py 24 22 32 > $OUT/stats_msm24.txt 2> $OUT/stats_msm24.err)
+ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm -- python3 $R/tools/msm_table_sweep.py 20 20 0 > $OUT/stats_msm.txt 2> $OUT/stats_msm.err && \
+ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm24 -- python3 $R/tools/msm_table_sweep.py 24 22 0 > $OUT/stats_msm24.txt 2> $OUT/stats_msm24.err)
 echo "final rc=$?"
 tail -3 $OUT/pytest_gpu.txt
 cat $OUT/smoke.txt

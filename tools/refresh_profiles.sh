@@ -1,7 +1,7 @@
 #!/bin/bash
 # After `gpurun -- bash tools/final_gpu_run.sh TAG`: copy what is judged from gpurun_out/TAG into profiles/ (newest file of each kind:
 # gpurun merges runs into the same directories).  usage: bash tools/refresh_profiles.sh [TAG] [ROUND]
-TAG=${1:-r03z}; R=${2:-r03}
+TAG=${1:-r04z}; R=${2:-r04}
 O=gpurun_out/$TAG
 for p in headline:stats_headline bench:stats msm:stats_msm msm24:stats_msm24; do
   n=${p%%:*}; d=${p##*:}
