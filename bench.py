@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--no-poly", action="store_true")
     ap.add_argument("--no-prover", action="store_true")
+    ap.add_argument("--no-dist-prover", action="store_true", help="skip the pm_plonk_prove_dist leg of the prover")
     ap.add_argument("--no-msm-extra", action="store_true",
                     help="skip the witness-like and batched MSM measurements (PMC passes: one MSM shape per mode)")
     ap.add_argument("--no-ntt-extra", action="store_true",
@@ -423,12 +424,17 @@ def main():
 
         res = msm_step()
         barrier()
-        ctx.profile(True)
+        # as for the headline: the timed loop runs with every timer off (an event pair is ~5 us of stream time, a dozen
+        # kernels per MSM), the kernels' durations come from a profiled loop of the same step right after it
         t0 = time.perf_counter()
         for _ in range(steps):
             res = msm_step()
         barrier()
         mdt = max_over_ranks(time.perf_counter() - t0)
+        ctx.profile(True)
+        for _ in range(steps):
+            msm_step()
+        barrier()
         mprof = ctx.profile_read()
         ctx.profile(False)
         # parity inside the bench: discrete-log identity (bases are known multiples of G)
@@ -724,6 +730,40 @@ def main():
         # two proofs in flight: a second context (own stream, own key and workspace) proving from a second host
         # thread over the same resident SRS -- one proof's NTT / quotient / opening phases and low-occupancy MSM
         # tails run under the other's accumulate kernels
+        # the same proof with EVERY vector split over the ranks by coefficient range (pm_plonk_*_dist): N = 1
+        # prices the decomposition itself (four size-n sub-coset transforms per coset form, each through the four-step
+        # transform with one rank); N > 1 is the real thing -- the library's RCCL all-gather and all-to-all
+        dist_leg = None
+        if not args.no_dist_prover and gn % (world * world) == 0:
+            try:
+                from plonk_prototype_amd.dist import DistGroup
+                dgrp = DistGroup(native=(world > 1 and native_comm), device=dev)
+                m_ = gn // world
+                t0 = time.perf_counter()
+                dkey = pa.prover.DistProverKey(circuit, ctx, dgrp)
+                dkey.commit(ck._bases)
+                ctx.sync()
+                t_dpre = time.perf_counter() - t0
+                d_wsl = pa.DeviceVector.from_host(ctx, np.ascontiguousarray(wit[:, dgrp.rank * m_:(dgrp.rank + 1) * m_]).reshape(-1, 4))
+                dproof = dkey.prove(ck._bases, d_wsl, pub_sparse)
+                d_times = []
+                barrier()
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    dkey.prove(ck._bases, d_wsl, pub_sparse)
+                    d_times.append(time.perf_counter() - t0)
+                barrier()
+                dist_leg = {"ms_per_proof": round(max_over_ranks(float(np.median(d_times))) * 1e3, 2), "world": world,
+                            "equals_the_replicated_prover_byte_for_byte": dproof.to_bytes() == proof.to_bytes(),
+                            "device_bytes_per_rank": dkey.device_bytes, "preprocess_ms": round(t_dpre * 1e3, 1),
+                            "exchange": ("library RCCL communicator" if world > 1 and native_comm else
+                                         f"torch.distributed ({backend})" if world > 1 else "none (one rank)"),
+                            "note": "pm_plonk_prove_dist: rows / coefficients [rank n / world, (rank + 1) n / world) of every vector per "
+                                    "rank, transforms as four-step NTTs over the ranks, nothing replicated"}
+                d_wsl.free()
+                dkey.free()
+            except Exception as e:                                   # noqa: BLE001
+                dist_leg = {"error": str(e)}
         two_ms = None
         if world == 1:
             import threading
@@ -760,6 +800,7 @@ def main():
                   "timing": f"median of {reps} proofs (mean {pmean * 1e3:.2f} ms, max {max(times) * 1e3:.2f} ms)",
                   "entry_point": "pm_plonk_prove (one C-ABI call)" if world == 1 else "pm_plonk_prove_sharded (one C-ABI call per rank)",
                   "two_contexts_ms_per_proof": round(two_ms, 2) if two_ms else None,
+                  "distributed": dist_leg,
                   "n_gpus": world, "scaling": "strong" if world > 1 else None,
                   "parallelism": ("one GPU" if world == 1 else
                                   f"rounds replicated on {world} ranks, every MSM split by coefficient range, "

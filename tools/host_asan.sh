@@ -4,9 +4,9 @@
 # CPU only -- GPU sanitizer runs are not available on this pool.   usage: bash tools/host_asan.sh
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
-TESTS="tests/test_msm_geometry.py tests/test_ntt_plan.py tests/test_abi.py tests/test_transcript.py"
+TESTS="tests/test_msm_geometry.py tests/test_ntt_plan.py tests/test_abi.py tests/test_transcript.py tests/test_domain_helpers.py"
 for SAN in address undefined; do
-  B=/tmp/plonk_${SAN}_build
+  B=$R/build_ab/san_${SAN}
   mkdir -p $B
   cd $R/plonk-prototype_amd/csrc
   EXTRA="-Xarch_host -fno-omit-frame-pointer"
@@ -20,5 +20,5 @@ for SAN in address undefined; do
   RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
   [ $SAN = undefined ] && RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
   cd $R
-  ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT PM_LIB_PATH=$B/libplonk_$SAN.so python -m pytest $TESTS -x -q -s
+  ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT PM_LIB_PATH=$B/libplonk_$SAN.so python -m pytest $TESTS -x -q -s -m "not gpu"
 done
