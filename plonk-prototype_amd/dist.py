@@ -132,6 +132,15 @@ class LocalGroup:
         self._barrier.wait()
         return out
 
+    def alltoall_host(self, rank: int, send: np.ndarray) -> np.ndarray:
+        """The same exchange on host arrays (equal length on every rank) -> this rank's receive buffer."""
+        per = send.shape[0] // self.world
+        self._send[rank] = send
+        self._barrier.wait()
+        out = np.concatenate([s[rank * per:(rank + 1) * per] for s in self._send])
+        self._barrier.wait()
+        return out
+
     def alltoall_tensors(self, rank: int, send, recv) -> int:
         """Block p of `recv` <- block `rank` of rank p's `send` (device tensors of equal size on every rank)."""
         import torch
@@ -191,12 +200,16 @@ class DistGroup:
     its own RCCL communicator (``Context.comm_init`` first)."""
 
     def __init__(self, rank: int | None = None, world: int | None = None, local: "LocalGroup | None" = None,
-                 device="cuda", native: bool = False):
-        import torch.distributed as tdist
-        self.local, self.device = local, device
+                 device="cuda", native: bool = False, host_staging_ctx: Context | None = None):
+        """host_staging_ctx (LocalGroup only): carry the all-to-all through host memory with this context's
+        ``pm_dev_download`` / ``pm_dev_upload`` instead of torch device copies -- for runs where torch cannot touch the GPU
+        (the host-AddressSanitizer build of the library: torch's CUDA initialisation fails under the preloaded runtime)."""
+        self.local, self.device, self._stage_ctx = local, device, host_staging_ctx
         if local is not None:
             self.world, self.rank = local.world, int(rank)
+            tdist = None
         else:
+            import torch.distributed as tdist
             self.world = tdist.get_world_size() if tdist.is_initialized() else 1
             self.rank = tdist.get_rank() if tdist.is_initialized() else 0
         self._ag = None if native else _lib.ALLGATHER_FN(self._allgather)
@@ -227,8 +240,15 @@ class DistGroup:
 
     def _alltoall(self, _user, d_send, d_recv, bytes_per_peer):
         try:
-            import torch
             nbytes = bytes_per_peer * self.world
+            if self.local is not None and self._stage_ctx is not None:
+                c = self._stage_ctx
+                host = np.empty(nbytes // 8, np.uint64)
+                c._check(c._lib.pm_dev_download(c._h, host.ctypes.data_as(C.c_void_p), C.c_void_p(d_send), nbytes))
+                got = self.local.alltoall_host(self.rank, host)
+                c._check(c._lib.pm_dev_upload(c._h, C.c_void_p(d_recv), got.ctypes.data_as(C.c_void_p), nbytes))
+                return 0
+            import torch
             send, recv = _dev_tensor(d_send, nbytes, self.device), _dev_tensor(d_recv, nbytes, self.device)
             if self.local is not None:
                 return self.local.alltoall_tensors(self.rank, send, recv)

@@ -66,6 +66,65 @@ def test_dist_prover_equals_single_gpu(ctx, log_n, world, mixed):
         assert nbytes <= (160 * n // world + 6 * 4 + 1) * 32, (r, nbytes)
 
 
+def test_dist_prover_public_inputs_on_every_rank(ctx):
+    """32 public inputs spread over all four ranks' rows (each rank scatters the ones in its slice; all bind the whole
+    list into the transcript), one of them with value zero and one position repeated."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+    n, world = 1 << 10, 4
+    rows = tuple(range(3, n, n // 32))
+    circuit, wit, pi = pa.synthetic.chain_circuit(n, 9, public_rows=rows)
+    srs = CpuOracle().g1_bases_arith(ints_to_limbs([77], 4)[0], ints_to_limbs([0x10001], 4)[0], n, 4)
+    pos, val = PR.sparse_public_inputs(pi)
+    assert len(pos) == 32
+    ck = pa.CommitKey(srs, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
+    single = PR.prove(pk, ck, wit, (pos, val)).to_bytes()
+    m = n // world
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            key = PR.DistProverKey(circuit, c, DistGroup(rank=r, local=g))
+            bases = pa.host.Bases(c, srs[r * m:(r + 1) * m])
+            key.commit(bases)
+            out = key.prove(bases, wit, (pos, val)).to_bytes()
+            key.free()
+            return out
+        finally:
+            c.close()
+    assert all(out == single for out in run_ranks(world, body))
+
+
+def test_dist_prover_with_host_staged_alltoall(ctx):
+    """The all-to-all carried through host memory by the library's own copies (no torch on the device): the variant the
+    host-AddressSanitizer run uses, where torch's CUDA initialisation is not available."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    n, world = 1 << 10, 4
+    circuit, wit, pi, srs = _inputs(n, True, 41)
+    ck = pa.CommitKey(srs, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
+    single = _blob(PR.prove(pk, ck, wit, pi), pk.verifier_key)
+    m = n // world
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            key = PR.DistProverKey(circuit, c, DistGroup(rank=r, local=g, host_staging_ctx=c))
+            bases = pa.host.Bases(c, srs[r * m:(r + 1) * m])
+            key.commit(bases)
+            out = _blob(key.prove(bases, wit, pi), key.verifier_key)
+            key.free()
+            return out
+        finally:
+            c.close()
+    assert all(out == single for out in run_ranks(world, body))
+
+
 def test_dist_prover_failure_does_not_block(ctx):
     """A public input outside the circuit on ONE rank: that rank gets PM_ERR_LENGTH, its peers PM_ERR_EXCHANGE from their
     next all-gather, nobody blocks, and the keys prove normally afterwards; a short commit-key slice likewise."""
