@@ -552,27 +552,19 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
     (void)block_exclusive_scan(cur, nb, wsum);
     SORT_T(2, 7);
   }
-  // A streamed partition requests tile t + 1 as soon as tile t's pairs have left the registers for the LDS stage: the
-  // loads (6 of a tile's 18 us when waited for at the top of the loop: first touch of the pairs in HBM) travel under the
-  // copy-out of tile t (r04; no registers added: the kernel sits at 116 of its 128)
-  u32 lk[SORT_IPT], lv[SORT_IPT];
-  auto load_tile = [&](u32 t_) {
-    const u32 base_ = t_ * SORT_TILE2_PAIRS;
-    const u32 cnt_ = size - base_ < SORT_TILE2_PAIRS ? size - base_ : SORT_TILE2_PAIRS;
-#pragma unroll
-    for (u32 q = 0; q < SORT_IPT; ++q) {
-      const u32 e = tid + q * SORT_THREADS;
-      const u64 pr = e < cnt_ ? src[base_ + e] : 0ull;
-      lk[q] = (u32)(pr >> 32) & lmask;
-      lv[q] = (u32)pr;
-    }
-  };
-  load_tile(0);
   for (u32 t = 0; t < ntile; ++t) {
     const u32 base = t * SORT_TILE2_PAIRS;
     const u32 cnt = size - base < SORT_TILE2_PAIRS ? size - base : SORT_TILE2_PAIRS;
     if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 0);   // tools/sort_bench: a full tile
     for (u32 b = tid; b < nb; b += SORT_THREADS) thist[b] = 0;
+    u32 lk[SORT_IPT], lv[SORT_IPT];
+#pragma unroll
+    for (u32 q = 0; q < SORT_IPT; ++q) {
+      const u32 e = tid + q * SORT_THREADS;
+      const u64 pr = e < cnt ? src[base + e] : 0ull;
+      lk[q] = (u32)(pr >> 32) & lmask;
+      lv[q] = (u32)pr;
+    }
     __syncthreads();
     if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 1);   // tools/sort_bench: a full tile
     u32 rk[SORT_IPT];
@@ -625,7 +617,6 @@ __global__ void __launch_bounds__(SORT_THREADS) msm_sort_local_kernel(const MsmG
       }
     __syncthreads();
     if (t == (ntile > 1 ? 1u : 0u)) SORT_T(2, 4);   // tools/sort_bench: a full tile
-    if (t + 1 < ntile) load_tile(t + 1);            // lk / lv are free: the next tile's pairs are in flight from here on
     if (ntile == 1) {
       for (u32 e = tid; e < cnt; e += SORT_THREADS) {
         keys_out[lo + e] = key_hi | stage_k[e];
