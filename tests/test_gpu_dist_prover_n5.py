@@ -66,6 +66,45 @@ def test_dist_prover_equals_single_gpu(ctx, log_n, world, mixed):
         assert nbytes <= (160 * n // world + 6 * 4 + 1) * 32, (r, nbytes)
 
 
+@pytest.mark.parametrize("log_n,world", [(10, 4), (12, 2)])
+def test_dist_prover_against_the_c_prover(oracle, log_n, world):
+    """Not only "equal to the library's other prover": every commitment and evaluation of the distributed proof, and the
+    verifier key, against the CPU prover composed from the C restatement (oracle/cpu_prover.py) with the same challenges --
+    and those challenges are the ones the verifier's side of the transcript derives from the proof bytes."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    from oracle import cpu_prover as CP
+    from oracle.cpu_oracle import ints_to_limbs
+    n = 1 << log_n
+    circuit, wit, pub = pa.synthetic.mixed_circuit(n, 200 + log_n)
+    srs = oracle.g1_bases_arith(ints_to_limbs([0xA5A5], 4)[0], ints_to_limbs([0x7FFFFFFF], 4)[0], n, 8)
+    m = n // world
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            key = PR.DistProverKey(circuit, c, DistGroup(rank=r, local=g))
+            bases = pa.host.Bases(c, srs[r * m:(r + 1) * m])
+            vk = key.commit(bases)
+            proof = key.prove(bases, wit, pub)
+            key.free()
+            return proof, vk
+        finally:
+            c.close()
+    proof, vk = run_ranks(world, body)[world - 1]
+    replay = PR.derive_challenges(PR.Proof.from_bytes(proof.to_bytes()), vk, n, pub, t_eval=PR.fr_from_limbs(proof.evaluations["t"]))
+    assert all(replay[k] == v for k, v in proof.challenges.items())
+    cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
+    exp = CP.prove(oracle, cpk, srs, wit, pub, proof.challenges, threads=8)
+    for k, v in exp["evaluations"].items():
+        assert np.array_equal(proof.evaluations[k], v), k
+    for k, v in exp["commitments"].items():
+        assert np.array_equal(proof.commitments[k], v), k
+    for k, v in CP.verifier_key(oracle, cpk, srs, threads=8).items():
+        assert np.array_equal(vk[k], v), k
+
+
 def test_dist_prover_public_inputs_on_every_rank(ctx):
     """32 public inputs spread over all four ranks' rows (each rank scatters the ones in its slice; all bind the whole
     list into the transcript), one of them with value zero and one position repeated."""
