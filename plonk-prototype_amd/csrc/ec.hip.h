@@ -174,18 +174,12 @@ struct Half {
   bool inf;
 };
 PM_DEV Fp fp_pair_swap(const Fp& v) {   // lanes 2k <-> 2k + 1
-#ifdef PM_DIAG_NO_DPP   // timing experiment only (wrong results): what the exchanges cost
-  return v;
-#endif
   Fp r;
 #pragma unroll
   for (int i = 0; i < 14; ++i) r.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.l[i], 0xB1, 0xF, 0xF, false);
   return r;
 }
 PM_DEV Fp fp_select(bool c, const Fp& a, const Fp& b) {   // c ? a : b
-#ifdef PM_DIAG_NO_SEL   // timing experiment only (wrong results): what the selects cost
-  return a;
-#endif
   Fp r;
 #pragma unroll
   for (int i = 0; i < 14; ++i) r.l[i] = c ? a.l[i] : b.l[i];

@@ -327,71 +327,6 @@ PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
 // issue slots) and the wave issues in order: one product alone leaves the SIMD idle between dependent
 // instructions unless other waves fill in -- kernels that run one or two waves per SIMD (the MSM's) want two
 // chains per wave (measured: DESIGN.md section 4).
-#ifdef PM_FE_SPLIT
-// Variant under test: the limb products a_i b_j of a column go to accumulators of their own (they depend on nothing but
-// the operands: an independent chain per column), and only the reduction terms q_i M_j run through the carried
-// accumulator -- four chains per wave instead of two, one more 64-bit addition per column and product.
-template <class P>
-PM_DEV void fe_mul2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, Fe<P>& r0, Fe<P>& r1) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q0[N], q1[N];
-  u64 acc0 = 0, acc1 = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    u64 p0 = 0, p1 = 0;
-#pragma unroll
-    for (int i = 0; i <= k; ++i) {
-      p0 += (u64)a0.l[i] * b0.l[k - i];
-      p1 += (u64)a1.l[i] * b1.l[k - i];
-    }
-#pragma unroll
-    for (int i = 0; i < k; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-    }
-    acc0 += p0;
-    acc1 += p1;
-    if (M.v[0] == 1u) {
-      q0[k] = (0u - (u32)acc0) & MASK;
-      q1[k] = (0u - (u32)acc1) & MASK;
-      acc0 += q0[k];
-      acc1 += q1[k];
-    } else {
-      q0[k] = ((u32)acc0 * NINV) & MASK;
-      q1[k] = ((u32)acc1 * NINV) & MASK;
-      acc0 += (u64)q0[k] * M.v[0];
-      acc1 += (u64)q1[k] * M.v[0];
-    }
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N - 1; ++k) {
-    u64 p0 = 0, p1 = 0;
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      p0 += (u64)a0.l[i] * b0.l[k - i];
-      p1 += (u64)a1.l[i] * b1.l[k - i];
-    }
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-    }
-    acc0 += p0;
-    acc1 += p1;
-    r0.l[k - N] = (u32)acc0 & MASK;
-    r1.l[k - N] = (u32)acc1 & MASK;
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-  r0.l[N - 1] = (u32)acc0;
-  r1.l[N - 1] = (u32)acc1;
-}
-#else
 template <class P>
 PM_DEV void fe_mul2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, Fe<P>& r0, Fe<P>& r1) {
   constexpr int N = P::N, W = P::W;
@@ -446,7 +381,6 @@ PM_DEV void fe_mul2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<
   r0.l[N - 1] = (u32)acc0;
   r1.l[N - 1] = (u32)acc1;
 }
-#endif
 // Three independent products in lock step (the third chain of a round that has three products to offer).
 template <class P>
 PM_DEV void fe_mul3(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, const Fe<P>& a2, const Fe<P>& b2,
