@@ -87,3 +87,50 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_local_group_collectives_on_the_cpu():
+    """dist.LocalGroup (ranks = threads of one process), the transport of the world-8 rehearsals and of the distributed
+    prover's callbacks, by itself on the CPU: the fixed-size message all-gather, the host-staged all-to-all and the
+    gather + fold with its abort marker at world 8 -- and the DistGroup all-gather callback driven through ctypes as
+    the library drives it."""
+    import ctypes as C
+    import threading
+    import plonk_prototype_amd as pa
+    from plonk_prototype_amd import _lib
+    from plonk_prototype_amd.dist import DistGroup, LocalGroup
+    from oracle.cpu_oracle import CpuOracle, ints_to_limbs
+    world = 8
+    g = LocalGroup(world, timeout=60)
+    o = CpuOracle()
+    G = o.g1_generator()
+    one = o.fp_to_mont(ints_to_limbs([1], 6))[0]
+    res = [None] * world
+
+    def body(r):
+        words = np.arange(_lib.COMM_MSG_WORDS, dtype=np.uint64) + 1000 * r
+        gathered = g.allgather_words(r, words)
+        send = (np.arange(world * 5, dtype=np.uint64) + 100 * r)           # block p goes to rank p
+        recv = g.alltoall_host(r, send)
+        part = np.zeros((2, 18), np.uint64)
+        part[0, :12], part[0, 12:] = o.g1_mul(G, ints_to_limbs([r + 1], 4)[0]), one
+        part[1, 6:12] = one                                                    # identity
+        folded = g.allgather_fold_many(r, part)
+        gave_up = g.allgather_fold_many(r, None if r == 3 else part)
+        # the callback the library calls (pm_allgather_fn): msg in, world x msg out
+        grp = DistGroup(rank=r, local=g)
+        msg = (C.c_uint64 * _lib.COMM_MSG_WORDS)(*([7 + r] * _lib.COMM_MSG_WORDS))
+        out = (C.c_uint64 * (_lib.COMM_MSG_WORDS * world))()
+        rc = grp._ag(None, msg, out)
+        res[r] = (gathered, recv, folded, gave_up, rc, [out[p * _lib.COMM_MSG_WORDS] for p in range(world)])
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+        assert not t.is_alive()
+    for r, (gathered, recv, folded, gave_up, rc, firsts) in enumerate(res):
+        assert gathered.shape == (world, _lib.COMM_MSG_WORDS) and all(gathered[p, 5] == 5 + 1000 * p for p in range(world))
+        assert recv.tolist() == [100 * p + 5 * r + i for p in range(world) for i in range(5)]
+        assert np.array_equal(pa.g1_to_affine(folded[0])[0], o.g1_mul(G, ints_to_limbs([36], 4)[0])) and pa.g1_to_affine(folded[1])[1]
+        assert gave_up is None and rc == 0 and firsts == [7 + p for p in range(world)]
