@@ -134,7 +134,15 @@ int main() {
     // a public input at gate 3 (PI enters the gate equation: a - c + PI = 0 no longer holds, but the
     // transcript must see it): other challenges than without
     REQUIRE(pk.prove(ck64, dwit, {PublicInput{3, one}}).challenges[0] != proof.challenges[0]);
-    std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial, ProverKey over %s)\n", pm_version());
+    // the distributed prover (pm_plonk_*_dist) on ONE rank -- the sub-coset decomposition without any exchange; the all-gather
+    // of one rank is a copy: the same proof and verifier key, byte for byte
+    pm_dist d1{1, 0, [](void*, const uint64_t* msg, uint64_t* gathered) -> int {
+                 std::memcpy(gathered, msg, PM_COMM_MSG_WORDS * sizeof(uint64_t));
+                 return 0;
+               }, nullptr, nullptr};
+    DistProverKey dpk(ctx, d1, sel, sigma, gn, ck64);
+    REQUIRE(dpk.prove(ck64, dwit).bytes == proof.bytes && dpk.verifier_key() == pk.verifier_key() && dpk.device_bytes() > 0);
+    std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial, ProverKey, DistProverKey over %s)\n", pm_version());
     return 0;
   } catch (const Error& e) {
     std::fprintf(stderr, "plonk_mi355x::Error %d: %s\n", e.code, e.what());

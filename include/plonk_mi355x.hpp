@@ -323,5 +323,69 @@ class ProverKey {
   std::array<G1Affine, PM_PLONK_VK_POINTS> verifier_key_;
 };
 
+// The same prover with every vector split over `dist.world` ranks by coefficient range (pm_plonk_*_dist, DESIGN.md
+// section 7.6): this rank is given its m = n / world rows of every selector column and of the permutation, its slice
+// [rank m, (rank + 1) m) of the commit key, and holds 1 / world of the key and workspace.  `dist` carries the two
+// collectives (both null: the context's RCCL communicator, pm_comm_init); every rank gets the same proof.
+class DistProverKey {
+ public:
+  DistProverKey(Context& ctx, const pm_dist& dist, const std::array<std::vector<Fr>, PM_PLONK_SELECTORS>& selector_slices,
+                const std::vector<int64_t>& sigma_index_slices, size_t n, const CommitKey& ck_slice,
+                const char* transcript_label = nullptr)
+      : ctx_(&ctx), dist_(dist), n_(n) {
+    const size_t m = n / dist.world;
+    const uint64_t* ptrs[PM_PLONK_SELECTORS];
+    for (int s = 0; s < PM_PLONK_SELECTORS; ++s) {
+      if (selector_slices[s].empty()) {
+        ptrs[s] = nullptr;
+        continue;
+      }
+      if (selector_slices[s].size() != m) throw Error(PM_ERR_LENGTH, "a selector slice must hold n / world rows");
+      ptrs[s] = selector_slices[s][0].data();
+    }
+    if (sigma_index_slices.size() != 4 * m) throw Error(PM_ERR_LENGTH, "sigma_index_slices must have 4 n / world entries");
+    ctx.check(pm_plonk_preprocess_dist(ctx.get(), &dist_, ptrs, sigma_index_slices.data(), n, &key_));
+    uint64_t vk[PM_PLONK_VK_POINTS][12];
+    int rc = pm_plonk_key_commit_dist(ctx.get(), &dist_, key_, ck_slice.bases(), transcript_label, vk);
+    if (rc) {
+      pm_plonk_dist_key_free(ctx.get(), key_);
+      key_ = nullptr;
+      ctx.check(rc);
+    }
+    for (int i = 0; i < PM_PLONK_VK_POINTS; ++i) std::copy(vk[i], vk[i] + 12, verifier_key_[i].begin());
+  }
+  ~DistProverKey() { if (key_) pm_plonk_dist_key_free(ctx_->get(), key_); }
+  DistProverKey(const DistProverKey&) = delete;
+  DistProverKey& operator=(const DistProverKey&) = delete;
+  size_t device_bytes() const { return pm_plonk_dist_key_bytes(key_); }
+  const std::array<G1Affine, PM_PLONK_VK_POINTS>& verifier_key() const { return verifier_key_; }
+  // witness_slices: this rank's [a | b | c | d] rows on the device (4 n / world); public inputs whole, the same on every rank
+  Proof prove(const CommitKey& ck_slice, const DevicePolynomial& witness_slices, const std::vector<PublicInput>& public_inputs = {},
+              bool bind_public_inputs = true) const {
+    if (witness_slices.len() != 4 * (n_ / dist_.world)) throw Error(PM_ERR_LENGTH, "the witness must hold 4 n / world wire values");
+    std::vector<uint64_t> pos, val;
+    for (const PublicInput& pi : public_inputs) {
+      pos.push_back(pi.position);
+      val.insert(val.end(), pi.value.begin(), pi.value.end());
+    }
+    pm_plonk_proof raw;
+    ctx_->check(pm_plonk_prove_dist(ctx_->get(), &dist_, key_, ck_slice.bases(), witness_slices.data(), pos.data(), val.data(),
+                                    pos.size(), bind_public_inputs ? 0u : PM_PLONK_UPSTREAM_TRANSCRIPT, &raw));
+    Proof p;
+    for (int i = 0; i < 11; ++i) std::copy(raw.commitments[i], raw.commitments[i] + 12, p.commitments[i].begin());
+    for (int i = 0; i < PM_PLONK_EVALS; ++i) std::copy(raw.evaluations[i], raw.evaluations[i] + 4, p.evaluations[i].begin());
+    for (int i = 0; i < PM_PLONK_CHALLENGES; ++i) std::copy(raw.challenges[i], raw.challenges[i] + 4, p.challenges[i].begin());
+    ctx_->check(pm_plonk_proof_to_bytes(&raw, p.bytes.data()));
+    return p;
+  }
+
+ private:
+  Context* ctx_;
+  pm_dist dist_;
+  size_t n_;
+  pm_dist_key* key_ = nullptr;
+  std::array<G1Affine, PM_PLONK_VK_POINTS> verifier_key_;
+};
+
 }  // namespace plonk_mi355x
 #endif  // PLONK_MI355X_HPP
