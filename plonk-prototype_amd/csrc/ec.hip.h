@@ -171,7 +171,9 @@ PM_DEV Xyzz xyzz_mul_small(const Xyzz& p, u32 k) {
 // P + P / P - P as xyzz_add / xyzz_double above; the `inf` flag is kept equal on both lanes.
 struct Half {
   Fp c0, c1;
-  bool inf;
+  u32 inf;   // 0 / 1.  A whole word: with `bool` the struct has three padding bytes, and hipcc copies them through SCRATCH
+             // on every assignment (scratch_load / s_waitcnt / scratch_store: two global-memory round trips per addition,
+             // exposed when one wave runs per SIMD -- r04, found in the ISA of msm_bucket_reduce_kernel)
 };
 PM_DEV Fp fp_pair_swap(const Fp& v) {   // lanes 2k <-> 2k + 1
   Fp r;
