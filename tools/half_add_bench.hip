@@ -28,6 +28,14 @@ __global__ void __launch_bounds__(64 * WAVES, 1) bench_kernel(const u32* seed, u
   if (mode == 0) {   // one chain: acc += b
 #pragma unroll 1
     for (u32 i = 0; i < iters; ++i) run = half_add(run, b, isB);
+  } else if (mode == 3) {   // as mode 1, the two waves of a SIMD (waves w and w + 4 of the workgroup) taking turns at the higher priority
+#pragma unroll 1
+    for (u32 i = 0; i < iters; ++i) {
+      if ((i + (threadIdx.x >> 8)) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+      run = half_add(run, b, isB);
+      sum = half_add(sum, run, isB);
+    }
+    __builtin_amdgcn_s_setprio(0);
   } else {           // the bucket loop's shape: running += b; sum += running
 #pragma unroll 1
     for (u32 i = 0; i < iters; ++i) {
@@ -80,5 +88,6 @@ int main() {
   run<8>(d_seed, 64, 0, "acc += b");
   run<4>(d_seed, 32, 1, "running += b; sum += running");
   run<8>(d_seed, 32, 1, "running += b; sum += running");
+  run<8>(d_seed, 32, 3, "... with alternating s_setprio");
   return 0;
 }
