@@ -206,248 +206,197 @@ PM_DEV Fe<P> fe_norm_full(const Fe<P>& a) {
 // Requires  N * max(a limb) * max(b limb) + (N-1) * 2^(2W) + 2^(64-W) < 2^64, i.e. with
 // b normalised (limbs <= 2^W + 8):  a limbs < 6 * 2^29 (Fr) / < 13 * 2^28 (Fp).
 // Result: limbs < 2^W (normalised), value < a*b/R + m.
-template <class P>
-PM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+//
+// r05: ONE dependent chain per product.  Written as plain `acc += a * b`, hipcc's Reassociate pass adds the late
+// operand of every column -- the shifted carry -- last: each column becomes a fresh chain from 0 plus a 64-bit
+// addition to fold the carry in (16 extra v_lshl_add_u64 per Fr product, 26 per Fp product, + moves).  Dependent
+// and independent v_mad_u64_u32 issue at the same rate at every occupancy (tools/ubench.hip,
+// profiles/r05_ubench.txt), so those additions buy nothing.  PM_KEEP gives every partial sum a second use (an
+// empty asm: no instruction), Reassociate can no longer linearise the column, and instruction selection folds each
+// product with the running accumulator into one v_mad_u64_u32 whose addend is the carry.  The asm is NOT volatile
+// (an input-only asm would be: ~150 ordering barriers per product, the scheduler could no longer sink loads to
+// their uses and several kernels went from 120 to 350+ VGPRs): it threads a token register `tok` (tied in / out)
+// that the product's last statement ties to the result's top limb, so the chain stays live and side-effect free.
+// Fr 228 -> 205 VALU instructions per product, Fp 507 -> 460; measured -7.5 % .. -10 % shader cycles per product
+// at 1, 2 and 4 waves per SIMD (tools/fe_mul_chain_ab.hip, profiles/r05_fe_mul_chain_ab.txt).  The mads as inline
+// asm (clang has no builtin) lose: the hazard recogniser pads every asm -> asm pair with s_nop.  Also measured and
+// not adopted there: the shift split into v_alignbit_b32 + 32-bit shift (VOP3 issues like the 64-bit shift), "+q"
+// through a mad, and for Fr the subtractive digit q' = acc mod 2^W with a signed accumulator (-2 % more at four
+// waves per SIMD, but it needs Ba * Bb < 3.5 where the NTT butterflies hand fe_mul limbs up to 5 * 2^29).
+// `make EXTRA=-DPM_FE_CHAIN=0` builds the r04 forms for A/B runs.
+#ifndef PM_FE_CHAIN
+#define PM_FE_CHAIN 1
+#endif
+#if PM_FE_CHAIN
+#define PM_KEEP(tok, x) asm("" : "+v"(tok) : "v"(x))
+#define PM_KEEP_INIT(tok) asm("" : "=v"(tok))
+#else
+#define PM_KEEP(tok, x)
+#define PM_KEEP_INIT(tok) tok = 0
+#endif
+PM_DEV void fe_mac(u64& acc, u32 a, u32 b, u32& tok) {
+  acc += (u64)a * b;
+  PM_KEEP(tok, acc);
+}
+
+// The reduction half shared by every product routine: K accumulators walk the 2N-1 columns in lock step;
+// `prod(k, acc)` adds the limb products of column k (in the order the caller wants them issued), this adds the
+// q * m terms, derives the quotient digit and shifts.  Statements of the K chains alternate, so two products of one
+// wave interleave instruction by instruction (kernels that run one or two waves per SIMD: DESIGN.md section 4).
+template <class P, int K, class F>
+PM_DEV void fe_mont_cols(F&& prod, Fe<P>* const (&r)[K]) {
   constexpr int N = P::N, W = P::W;
   constexpr u32 MASK = Consts<P>::MASK;
   constexpr Limbs<N> M = Consts<P>::mod_limbs();
   constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q[N];
-  Fe<P> t;
-  u64 acc = 0;
+  u32 q[K][N];
+  u64 acc[K];
+  u32 tok;
+  PM_KEEP_INIT(tok);
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
+  for (int c = 0; c < K; ++c) acc[c] = 0;
 #pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (u64)a.l[i] * b.l[k - i];
+  for (int k = 0; k < 2 * N - 1; ++k) {
+    prod(k, acc, tok);
+    if (k < N) {
 #pragma unroll
-    for (int i = 0; i < k; ++i) acc += (u64)q[i] * M.v[k - i];
-    if (M.v[0] == 1u) {  // Fr: m = 1 mod 2^W, -m^-1 = -1
-      q[k] = (0u - (u32)acc) & MASK;
-      acc += q[k];
+      for (int i = 0; i < k; ++i)
+#pragma unroll
+        for (int c = 0; c < K; ++c) fe_mac(acc[c], q[c][i], M.v[k - i], tok);
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        if (M.v[0] == 1u) {  // Fr: m = 1 mod 2^W, -m^-1 = -1
+          q[c][k] = (0u - (u32)acc[c]) & MASK;
+#if PM_FE_CHAIN
+          acc[c] += (u64)MASK;  // (acc + q) >> W == (acc + 2^W - 1) >> W: the carry does not wait for q
+#else
+          acc[c] += q[c][k];
+#endif
+        } else {
+          q[c][k] = ((u32)acc[c] * NINV) & MASK;
+          fe_mac(acc[c], q[c][k], M.v[0], tok);
+        }
+        acc[c] >>= W;
+      }
     } else {
-      q[k] = ((u32)acc * NINV) & MASK;
-      acc += (u64)q[k] * M.v[0];
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i)
+#pragma unroll
+        for (int c = 0; c < K; ++c) fe_mac(acc[c], q[c][i], M.v[k - i], tok);
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        r[c]->l[k - N] = (u32)acc[c] & MASK;
+        acc[c] >>= W;
+      }
     }
-    acc >>= W;
   }
 #pragma unroll
-  for (int k = N; k < 2 * N - 1; ++k) {
+  for (int c = 0; c < K; ++c) r[c]->l[N - 1] = (u32)acc[c];
+#if PM_FE_CHAIN
+  asm("" : "+v"(r[0]->l[N - 1]) : "v"(tok));  // the token chain ends in a live value
+#endif
+}
+// limb products a_i b_(k-i) of column k
+template <class P>
+PM_DEV void fe_col_mul(int k, u64& acc, const Fe<P>& a, const Fe<P>& b, u32& tok) {
+  constexpr int N = P::N;
 #pragma unroll
-    for (int i = k - N + 1; i < N; ++i) acc += (u64)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) acc += (u64)q[i] * M.v[k - i];
-    t.l[k - N] = (u32)acc & MASK;
-    acc >>= W;
+  for (int i = 0; i < N; ++i) {
+    const int j = k - i;
+    if (j < 0 || j >= N) continue;
+    fe_mac(acc, a.l[i], b.l[j], tok);
   }
-  t.l[N - 1] = (u32)acc;
+}
+// ... of a^2 with the cross terms taken once against the pre-doubled copy d = 2a
+template <class P>
+PM_DEV void fe_col_sqr(int k, u64& acc, const Fe<P>& a, const u32 (&d)[P::N], u32& tok) {
+  constexpr int N = P::N;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int j = k - i;
+    if (j < 0 || j >= N || i > j) continue;
+    fe_mac(acc, a.l[i], (i == j) ? a.l[i] : d[j], tok);
+  }
+}
+
+template <class P>
+PM_DEV Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> t;
+  Fe<P>* const out[1] = {&t};
+  fe_mont_cols<P, 1>([&](int k, u64* acc, u32& tok) { fe_col_mul<P>(k, acc[0], a, b, tok); }, out);
   return t;
 }
 // a * b0 / R for a one-limb b0 (< 2^W): the reduction half of fe_mul only (N + N(N-1) limb products instead of
 // 2 N^2 - N).  Same bounds and result class as fe_mul.  Used for Montgomery -> integer: x 2^256 * 2^5 / 2^261.
 template <class P>
 PM_DEV Fe<P> fe_mul_limb(const Fe<P>& a, u32 b0) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q[N];
   Fe<P> t;
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    acc += (u64)a.l[k] * b0;
-#pragma unroll
-    for (int i = 0; i < k; ++i) acc += (u64)q[i] * M.v[k - i];
-    if (M.v[0] == 1u) {
-      q[k] = (0u - (u32)acc) & MASK;
-      acc += q[k];
-    } else {
-      q[k] = ((u32)acc * NINV) & MASK;
-      acc += (u64)q[k] * M.v[0];
-    }
-    acc >>= W;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N - 1; ++k) {
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) acc += (u64)q[i] * M.v[k - i];
-    t.l[k - N] = (u32)acc & MASK;
-    acc >>= W;
-  }
-  t.l[N - 1] = (u32)acc;
+  Fe<P>* const out[1] = {&t};
+  fe_mont_cols<P, 1>(
+      [&](int k, u64* acc, u32& tok) {
+        if (k < P::N) fe_mac(acc[0], a.l[k], b0, tok);
+      },
+      out);
   return t;
 }
 // a^2 with the cross terms taken once against a pre-doubled copy: N(N+1)/2 products instead of
 // N^2 for the a*a part (the reduction part is unchanged).  Same bounds as fe_mul(a, a).
 template <class P>
 PM_DEV Fe<P> fe_sqr(const Fe<P>& a) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q[N], d[N];
+  u32 d[P::N];
+#pragma unroll
+  for (int i = 0; i < P::N; ++i) d[i] = a.l[i] << 1;
   Fe<P> t;
-#pragma unroll
-  for (int i = 0; i < N; ++i) d[i] = a.l[i] << 1;
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < 2 * N - 1; ++k) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int j = k - i;
-      if (j < 0 || j >= N || i > j) continue;
-      if (i == j)
-        acc += (u64)a.l[i] * a.l[i];
-      else
-        acc += (u64)a.l[i] * d[j];
-    }
-    if (k < N) {
-#pragma unroll
-      for (int i = 0; i < k; ++i) acc += (u64)q[i] * M.v[k - i];
-      if (M.v[0] == 1u) {
-        q[k] = (0u - (u32)acc) & MASK;
-        acc += q[k];
-      } else {
-        q[k] = ((u32)acc * NINV) & MASK;
-        acc += (u64)q[k] * M.v[0];
-      }
-    } else {
-#pragma unroll
-      for (int i = k - N + 1; i < N; ++i) acc += (u64)q[i] * M.v[k - i];
-      t.l[k - N] = (u32)acc & MASK;
-    }
-    acc >>= W;
-  }
-  t.l[N - 1] = (u32)acc;
+  Fe<P>* const out[1] = {&t};
+  fe_mont_cols<P, 1>([&](int k, u64* acc, u32& tok) { fe_col_sqr<P>(k, acc[0], a, d, tok); }, out);
   return t;
 }
 
 // Two independent products / squarings in lock step: the same arithmetic as fe_mul / fe_sqr, the statements of
-// the two interleaved column by column.  A column is a chain of dependent v_mad_u64_u32 (result latency ~3
-// issue slots) and the wave issues in order: one product alone leaves the SIMD idle between dependent
-// instructions unless other waves fill in -- kernels that run one or two waves per SIMD (the MSM's) want two
-// chains per wave (measured: DESIGN.md section 4).
+// the two interleaved.  A wave issues in order and one VALU instruction per ~5.5 cycles when alone on its SIMD
+// (profiles/r05_ubench.txt): kernels that run one or two waves per SIMD (the MSM's) want two chains per wave
+// (measured: DESIGN.md section 4).
 template <class P>
 PM_DEV void fe_mul2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, Fe<P>& r0, Fe<P>& r1) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q0[N], q1[N];
-  u64 acc0 = 0, acc1 = 0;
+  constexpr int N = P::N;
+  Fe<P> t0, t1;  // the outputs may alias the inputs
+  Fe<P>* const out[2] = {&t0, &t1};
+  fe_mont_cols<P, 2>(
+      [&](int k, u64* acc, u32& tok) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) {
-      acc0 += (u64)a0.l[i] * b0.l[k - i];
-      acc1 += (u64)a1.l[i] * b1.l[k - i];
-    }
-#pragma unroll
-    for (int i = 0; i < k; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-    }
-    if (M.v[0] == 1u) {
-      q0[k] = (0u - (u32)acc0) & MASK;
-      q1[k] = (0u - (u32)acc1) & MASK;
-      acc0 += q0[k];
-      acc1 += q1[k];
-    } else {
-      q0[k] = ((u32)acc0 * NINV) & MASK;
-      q1[k] = ((u32)acc1 * NINV) & MASK;
-      acc0 += (u64)q0[k] * M.v[0];
-      acc1 += (u64)q1[k] * M.v[0];
-    }
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N - 1; ++k) {
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)a0.l[i] * b0.l[k - i];
-      acc1 += (u64)a1.l[i] * b1.l[k - i];
-    }
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-    }
-    r0.l[k - N] = (u32)acc0 & MASK;
-    r1.l[k - N] = (u32)acc1 & MASK;
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-  r0.l[N - 1] = (u32)acc0;
-  r1.l[N - 1] = (u32)acc1;
+        for (int i = 0; i < N; ++i) {
+          const int j = k - i;
+          if (j < 0 || j >= N) continue;
+          fe_mac(acc[0], a0.l[i], b0.l[j], tok);
+          fe_mac(acc[1], a1.l[i], b1.l[j], tok);
+        }
+      },
+      out);
+  r0 = t0;
+  r1 = t1;
 }
 // Three independent products in lock step (the third chain of a round that has three products to offer).
 template <class P>
 PM_DEV void fe_mul3(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<P>& b1, const Fe<P>& a2, const Fe<P>& b2,
                     Fe<P>& r0, Fe<P>& r1, Fe<P>& r2) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q0[N], q1[N], q2[N];
-  u64 acc0 = 0, acc1 = 0, acc2 = 0;
+  constexpr int N = P::N;
+  Fe<P> t0, t1, t2;
+  Fe<P>* const out[3] = {&t0, &t1, &t2};
+  fe_mont_cols<P, 3>(
+      [&](int k, u64* acc, u32& tok) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) {
-      acc0 += (u64)a0.l[i] * b0.l[k - i];
-      acc1 += (u64)a1.l[i] * b1.l[k - i];
-      acc2 += (u64)a2.l[i] * b2.l[k - i];
-    }
-#pragma unroll
-    for (int i = 0; i < k; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-      acc2 += (u64)q2[i] * M.v[k - i];
-    }
-    if (M.v[0] == 1u) {
-      q0[k] = (0u - (u32)acc0) & MASK;
-      q1[k] = (0u - (u32)acc1) & MASK;
-      q2[k] = (0u - (u32)acc2) & MASK;
-      acc0 += q0[k];
-      acc1 += q1[k];
-      acc2 += q2[k];
-    } else {
-      q0[k] = ((u32)acc0 * NINV) & MASK;
-      q1[k] = ((u32)acc1 * NINV) & MASK;
-      q2[k] = ((u32)acc2 * NINV) & MASK;
-      acc0 += (u64)q0[k] * M.v[0];
-      acc1 += (u64)q1[k] * M.v[0];
-      acc2 += (u64)q2[k] * M.v[0];
-    }
-    acc0 >>= W;
-    acc1 >>= W;
-    acc2 >>= W;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N - 1; ++k) {
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)a0.l[i] * b0.l[k - i];
-      acc1 += (u64)a1.l[i] * b1.l[k - i];
-      acc2 += (u64)a2.l[i] * b2.l[k - i];
-    }
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-      acc2 += (u64)q2[i] * M.v[k - i];
-    }
-    r0.l[k - N] = (u32)acc0 & MASK;
-    r1.l[k - N] = (u32)acc1 & MASK;
-    r2.l[k - N] = (u32)acc2 & MASK;
-    acc0 >>= W;
-    acc1 >>= W;
-    acc2 >>= W;
-  }
-  r0.l[N - 1] = (u32)acc0;
-  r1.l[N - 1] = (u32)acc1;
-  r2.l[N - 1] = (u32)acc2;
+        for (int i = 0; i < N; ++i) {
+          const int j = k - i;
+          if (j < 0 || j >= N) continue;
+          fe_mac(acc[0], a0.l[i], b0.l[j], tok);
+          fe_mac(acc[1], a1.l[i], b1.l[j], tok);
+          fe_mac(acc[2], a2.l[i], b2.l[j], tok);
+        }
+      },
+      out);
+  r0 = t0;
+  r1 = t1;
+  r2 = t2;
 }
 // r0 = (a0 b0 + c0 d0) / R with ONE reduction for the two products (both go into the same column accumulators: a
 // difference of products costs 3 N^2 limb products instead of 4 N^2 when the subtrahend is negated limb-wise first),
@@ -456,118 +405,48 @@ PM_DEV void fe_mul3(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& a1, const Fe<
 template <class P>
 PM_DEV void fe_mma2(const Fe<P>& a0, const Fe<P>& b0, const Fe<P>& c0, const Fe<P>& d0, const Fe<P>& a1, const Fe<P>& b1,
                     Fe<P>& r0, Fe<P>& r1) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q0[N], q1[N];
-  u64 acc0 = 0, acc1 = 0;
+  constexpr int N = P::N;
+  Fe<P> t0, t1;
+  Fe<P>* const out[2] = {&t0, &t1};
+  fe_mont_cols<P, 2>(
+      [&](int k, u64* acc, u32& tok) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) {
-      acc0 += (u64)a0.l[i] * b0.l[k - i];
-      acc1 += (u64)a1.l[i] * b1.l[k - i];
-      acc0 += (u64)c0.l[i] * d0.l[k - i];
-    }
-#pragma unroll
-    for (int i = 0; i < k; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-    }
-    if (M.v[0] == 1u) {
-      q0[k] = (0u - (u32)acc0) & MASK;
-      q1[k] = (0u - (u32)acc1) & MASK;
-      acc0 += q0[k];
-      acc1 += q1[k];
-    } else {
-      q0[k] = ((u32)acc0 * NINV) & MASK;
-      q1[k] = ((u32)acc1 * NINV) & MASK;
-      acc0 += (u64)q0[k] * M.v[0];
-      acc1 += (u64)q1[k] * M.v[0];
-    }
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N - 1; ++k) {
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)a0.l[i] * b0.l[k - i];
-      acc1 += (u64)a1.l[i] * b1.l[k - i];
-      acc0 += (u64)c0.l[i] * d0.l[k - i];
-    }
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      acc0 += (u64)q0[i] * M.v[k - i];
-      acc1 += (u64)q1[i] * M.v[k - i];
-    }
-    r0.l[k - N] = (u32)acc0 & MASK;
-    r1.l[k - N] = (u32)acc1 & MASK;
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-  r0.l[N - 1] = (u32)acc0;
-  r1.l[N - 1] = (u32)acc1;
+        for (int i = 0; i < N; ++i) {
+          const int j = k - i;
+          if (j < 0 || j >= N) continue;
+          fe_mac(acc[0], a0.l[i], b0.l[j], tok);
+          fe_mac(acc[1], a1.l[i], b1.l[j], tok);
+          fe_mac(acc[0], c0.l[i], d0.l[j], tok);
+        }
+      },
+      out);
+  r0 = t0;
+  r1 = t1;
 }
 template <class P>
 PM_DEV void fe_sqr2(const Fe<P>& a0, const Fe<P>& a1, Fe<P>& r0, Fe<P>& r1) {
-  constexpr int N = P::N, W = P::W;
-  constexpr u32 MASK = Consts<P>::MASK;
-  constexpr Limbs<N> M = Consts<P>::mod_limbs();
-  constexpr u32 NINV = Consts<P>::neg_inv();
-  u32 q0[N], q1[N], d0[N], d1[N];
+  constexpr int N = P::N;
+  u32 d0[N], d1[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     d0[i] = a0.l[i] << 1;
     d1[i] = a1.l[i] << 1;
   }
-  u64 acc0 = 0, acc1 = 0;
+  Fe<P> t0, t1;
+  Fe<P>* const out[2] = {&t0, &t1};
+  fe_mont_cols<P, 2>(
+      [&](int k, u64* acc, u32& tok) {
 #pragma unroll
-  for (int k = 0; k < 2 * N - 1; ++k) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int j = k - i;
-      if (j < 0 || j >= N || i > j) continue;
-      if (i == j) {
-        acc0 += (u64)a0.l[i] * a0.l[i];
-        acc1 += (u64)a1.l[i] * a1.l[i];
-      } else {
-        acc0 += (u64)a0.l[i] * d0[j];
-        acc1 += (u64)a1.l[i] * d1[j];
-      }
-    }
-    if (k < N) {
-#pragma unroll
-      for (int i = 0; i < k; ++i) {
-        acc0 += (u64)q0[i] * M.v[k - i];
-        acc1 += (u64)q1[i] * M.v[k - i];
-      }
-      if (M.v[0] == 1u) {
-        q0[k] = (0u - (u32)acc0) & MASK;
-        q1[k] = (0u - (u32)acc1) & MASK;
-        acc0 += q0[k];
-        acc1 += q1[k];
-      } else {
-        q0[k] = ((u32)acc0 * NINV) & MASK;
-        q1[k] = ((u32)acc1 * NINV) & MASK;
-        acc0 += (u64)q0[k] * M.v[0];
-        acc1 += (u64)q1[k] * M.v[0];
-      }
-    } else {
-#pragma unroll
-      for (int i = k - N + 1; i < N; ++i) {
-        acc0 += (u64)q0[i] * M.v[k - i];
-        acc1 += (u64)q1[i] * M.v[k - i];
-      }
-      r0.l[k - N] = (u32)acc0 & MASK;
-      r1.l[k - N] = (u32)acc1 & MASK;
-    }
-    acc0 >>= W;
-    acc1 >>= W;
-  }
-  r0.l[N - 1] = (u32)acc0;
-  r1.l[N - 1] = (u32)acc1;
+        for (int i = 0; i < N; ++i) {
+          const int j = k - i;
+          if (j < 0 || j >= N || i > j) continue;
+          fe_mac(acc[0], a0.l[i], (i == j) ? a0.l[i] : d0[j], tok);
+          fe_mac(acc[1], a1.l[i], (i == j) ? a1.l[i] : d1[j], tok);
+        }
+      },
+      out);
+  r0 = t0;
+  r1 = t1;
 }
 
 // Cheap reduction without a Montgomery product: x (limbs < 2^32, value < 2^(W N)) -> normalised
