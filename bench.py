@@ -48,6 +48,84 @@ class stdout_to_stderr:
         return False
 
 
+class LineEmitter:
+    """The ONE JSON line.  `emit(obj)` writes it to the saved stdout descriptor exactly once per process, whoever calls
+    first (the main thread at the end, or the watchdog): a lock and a printed flag, so a watchdog that fires while the
+    main thread is printing cannot produce a second line."""
+
+    def __init__(self, fd):
+        import threading
+        self.fd, self.lock, self.printed = fd, threading.Lock(), False
+
+    def emit(self, obj) -> bool:
+        with self.lock:
+            if self.printed:
+                return False
+            self.printed = True
+            sys.stdout.flush()
+            os.write(self.fd, (json.dumps(obj) + "\n").encode())
+            return True
+
+
+class Watchdog:
+    """N > 1: a collective that never returns has no other way out.  Armed BEFORE the first collective (r04 armed it after
+    the headline: a desynchronised communicator setup hung with no line and no exit).  `extend(seconds, phase)` moves the
+    deadline when a phase completes; when it passes, `on_timeout(phase)` runs (rank 0 prints the line with what there is)
+    and EVERY rank leaves with a NON-ZERO code -- a hang must not read as success (r04 exited 0)."""
+    EXIT_CODE = 3
+
+    def __init__(self, seconds, on_timeout, phase="startup", exit_fn=os._exit):
+        import threading
+        self._deadline, self._phase = time.monotonic() + seconds, phase
+        self._done, self._lock = threading.Event(), threading.Lock()
+        self._on_timeout, self._exit = on_timeout, exit_fn
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def extend(self, seconds, phase):
+        with self._lock:
+            self._deadline, self._phase = time.monotonic() + seconds, phase
+
+    def finish(self):
+        self._done.set()
+
+    def _run(self):
+        while not self._done.wait(0.2):
+            with self._lock:
+                late, phase = time.monotonic() > self._deadline, self._phase
+            if late:
+                try:
+                    self._on_timeout(phase)
+                finally:
+                    self._exit(self.EXIT_CODE)
+                return
+
+
+def agree(dist, ok: bool, device) -> bool:
+    """True iff `ok` on EVERY rank: one all_reduce(MIN) that every rank reaches whatever happened to it locally, so no
+    rank skips a collective its peers are waiting in."""
+    import torch
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def setup_native_comm(ctx, rank, world, dist, coll_dev, log=lambda s: None) -> bool:
+    """Create the library's RCCL communicator on every rank, or on none.  ctx.comm_init broadcasts rank 0's (status, id)
+    unconditionally, so a failing id creation cannot leave the ranks in different collectives; the all_reduce(MIN) then
+    settles whether EVERY rank has a communicator -- if not, the ones that have one drop it and all use torch.distributed."""
+    try:
+        with stdout_to_stderr():
+            ctx.comm_init(rank, world, coll_dev)
+        ok_local = True
+    except Exception as e:                                   # noqa: BLE001
+        log(f"[bench] rank {rank}: pm_comm_init failed ({e}); using torch.distributed")
+        ok_local = False
+    native = agree(dist, ok_local, coll_dev)
+    if not native and ok_local:
+        ctx.comm_destroy()
+    return native
+
+
 def main():
     # stdout carries exactly ONE line, the result: file descriptor 1 points at stderr for the whole run (RCCL, gloo and the
     # HIP runtime print banners on stdout from native code, on every rank), and the JSON line goes to the saved descriptor
@@ -78,6 +156,9 @@ def main():
                     help="gates of the CPU-baseline proof (2^18: ~8 s on 16 threads; 2^20, the GPU leg's size: ~35 s)")
     ap.add_argument("--leg-timeout", type=int, default=420,
                     help="N > 1: seconds the sharded MSM / prover legs may take before the watchdog prints the line without them")
+    ap.add_argument("--startup-timeout", type=int, default=600,
+                    help="N > 1: seconds the process group, the communicator and the headline may take before the watchdog "
+                         "ends every rank with a non-zero code (armed before the first collective)")
     ap.add_argument("--fourstep-log-n", type=int, default=0,
                     help="N > 1 only, off by default: also time ONE 2^K transform split over the ranks "
                          "(pm_fr_ntt_fourstep_dev, SURVEY 8f N5) through the library's RCCL communicator")
@@ -104,6 +185,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    emitter = LineEmitter(json_fd)
+    state = {"emit": None}             # set once the headline exists: the full line with the legs that have finished
+    dog = None
+    if world > 1:
+        def on_timeout(phase):
+            note = (f"watchdog: phase '{phase}' did not finish in time (a collective that never returned?); line printed by the "
+                    f"watchdog with what had finished; every rank exits with code {Watchdog.EXIT_CODE}")
+            print(f"[bench] rank {rank}: {note}", file=sys.stderr, flush=True)
+            if rank == 0:
+                if state["emit"]:
+                    state["emit"](note)
+                else:
+                    emitter.emit({"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": None, "unit": "butterflies/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                                  "note": note})
+        dog = Watchdog(args.startup_timeout, on_timeout, "process group + communicator + headline")
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -133,18 +231,7 @@ def main():
     # fails on any rank, every rank falls back to torch.distributed for the 2.3 KB all-gathers (same fold)
     native_comm = False
     if world > 1 and backend == "nccl":
-        try:
-            with stdout_to_stderr():
-                ctx.comm_init(rank, world, coll_dev)
-            ok_local = 1
-        except Exception as e:                                   # noqa: BLE001
-            print(f"[bench] rank {rank}: pm_comm_init failed ({e}); using torch.distributed", file=sys.stderr)
-            ok_local = 0
-        flag = torch.tensor([ok_local], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        native_comm = bool(flag.item())
-        if not native_comm and ok_local:
-            ctx.comm_destroy()
+        native_comm = setup_native_comm(ctx, rank, world, dist, coll_dev, lambda m_: print(m_, file=sys.stderr, flush=True))
         # self-diagnosing first multi-GPU run: every rank says what communicator it ended up with
         import ctypes as _C
         _r, _w = _C.c_int(-1), _C.c_int(-1)
@@ -278,19 +365,11 @@ def main():
                "next_rows": legs.get("poly"), "prover": legs.get("prover")}
         if note:
             out["note"] = note
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return emitter.emit(out)
 
-    import threading
-    legs_done = threading.Event()
-    if world > 1:
-        def watchdog():
-            if not legs_done.wait(args.leg_timeout):
-                if rank == 0:
-                    emit_line(f"the multi-GPU legs did not finish within {args.leg_timeout} s (a collective that never "
-                              f"returned?): line printed by the watchdog with the legs that had finished")
-                os._exit(0)   # every rank leaves the same way: the line above says what happened
-        threading.Thread(target=watchdog, daemon=True).start()
+    state["emit"] = emit_line
+    if dog:
+        dog.extend(args.leg_timeout, "multi-GPU legs (sharded MSM / prover)")
 
     # ------------------------------------------------------------------ NTT extras (rank 0): SURVEY 8d
     ntt_extra = None
@@ -735,6 +814,13 @@ def main():
         # transform with one rank); N > 1 is the real thing -- the library's RCCL all-gather and all-to-all
         dist_leg = None
         if not args.no_dist_prover and gn % (world * world) == 0:
+            # Every phase that holds collectives runs under try / except on every rank and is followed by an agreement
+            # (all_reduce MIN, which every rank reaches): a rank whose phase failed never leaves its peers waiting in a
+            # barrier it skipped -- either all ranks go on, or all record the error.
+            def all_ok(ok_):
+                return agree(dist, ok_, coll_dev) if world > 1 else ok_
+            dkey = d_wsl = dproof = None
+            err, d_times, t_dpre = None, [], 0.0
             try:
                 from plonk_prototype_amd.dist import DistGroup
                 dgrp = DistGroup(native=(world > 1 and native_comm), device=dev)
@@ -746,24 +832,37 @@ def main():
                 t_dpre = time.perf_counter() - t0
                 d_wsl = pa.DeviceVector.from_host(ctx, np.ascontiguousarray(wit[:, dgrp.rank * m_:(dgrp.rank + 1) * m_]).reshape(-1, 4))
                 dproof = dkey.prove(ck._bases, d_wsl, pub_sparse)
-                d_times = []
-                barrier()
-                for _ in range(5):
-                    t0 = time.perf_counter()
-                    dkey.prove(ck._bases, d_wsl, pub_sparse)
-                    d_times.append(time.perf_counter() - t0)
-                barrier()
-                dist_leg = {"ms_per_proof": round(max_over_ranks(float(np.median(d_times))) * 1e3, 2), "world": world,
-                            "equals_the_replicated_prover_byte_for_byte": dproof.to_bytes() == proof.to_bytes(),
-                            "device_bytes_per_rank": dkey.device_bytes, "preprocess_ms": round(t_dpre * 1e3, 1),
-                            "exchange": ("library RCCL communicator" if world > 1 and native_comm else
-                                         f"torch.distributed ({backend})" if world > 1 else "none (one rank)"),
-                            "note": "pm_plonk_prove_dist: rows / coefficients [rank n / world, (rank + 1) n / world) of every vector per "
-                                    "rank, transforms as four-step NTTs over the ranks, nothing replicated"}
-                d_wsl.free()
-                dkey.free()
             except Exception as e:                                   # noqa: BLE001
-                dist_leg = {"error": str(e)}
+                err = f"setup: {e}"
+            if all_ok(err is None):
+                barrier()
+                try:
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        dkey.prove(ck._bases, d_wsl, pub_sparse)
+                        d_times.append(time.perf_counter() - t0)
+                except Exception as e:                               # noqa: BLE001
+                    err = f"timed proofs: {e}"
+                if all_ok(err is None):
+                    barrier()
+                    dstats = dkey.exchange_stats() if hasattr(dkey, "exchange_stats") else None
+                    dist_leg = {"ms_per_proof": round(max_over_ranks(float(np.median(d_times))) * 1e3, 2), "world": world,
+                                "equals_the_replicated_prover_byte_for_byte": dproof.to_bytes() == proof.to_bytes(),
+                                "device_bytes_per_rank": dkey.device_bytes, "preprocess_ms": round(t_dpre * 1e3, 1),
+                                "exchanges_per_proof": dstats,
+                                "exchange": ("library RCCL communicator" if world > 1 and native_comm else
+                                             f"torch.distributed ({backend})" if world > 1 else "none (one rank)"),
+                                "note": "pm_plonk_prove_dist: rows / coefficients [rank n / world, (rank + 1) n / world) of every vector per "
+                                        "rank, transforms as four-step NTTs over the ranks, nothing replicated"}
+            if dist_leg is None:
+                dist_leg = {"error": err or "a peer rank failed"}
+            try:
+                if d_wsl is not None:
+                    d_wsl.free()
+                if dkey is not None:
+                    dkey.free()
+            except Exception:                                        # noqa: BLE001
+                pass
         two_ms = None
         if world == 1:
             import threading
@@ -950,7 +1049,8 @@ def main():
             cpu["msm_single_thread_sample"] = f"one 2^{s1n.bit_length() - 1}-point Pippenger MSM on 1 thread ({t1msm:.1f} s)"
 
     legs.update(cpu=cpu, ntt_extra=ntt_extra, fourstep=fourstep, msm=msm, msm_large=msm_large, poly=poly, prover=prover)
-    legs_done.set()
+    if dog:
+        dog.finish()
     if rank == 0:
         emit_line()
     ctx.close()

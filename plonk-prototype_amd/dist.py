@@ -176,6 +176,7 @@ class LocalGroup:
                 self._barrier.wait()               # the peers have read this rank's send half
                 return 0 if ok else 1
             except Exception:                      # never raise through the C frame (a broken barrier included)
+                self._barrier.abort()              # the peers fail at once instead of waiting out the barrier's timeout
                 return 1
         return _lib.ALLTOALL_FN(cb)
 
@@ -236,7 +237,17 @@ class DistGroup:
                 out[:] = torch.stack(parts).cpu().numpy().view(np.uint64)
             return 0
         except Exception:            # never unwind through the C frames
+            self._abort_local()
             return 1
+
+    def _abort_local(self):
+        """A rank of a LocalGroup that fails outside the barrier (a bad pointer, a torch error) breaks the barrier for
+        its peers: they get BrokenBarrierError -> 1 at once instead of after the barrier's 600 s timeout."""
+        if self.local is not None:
+            try:
+                self.local._barrier.abort()
+            except Exception:        # noqa: BLE001
+                pass
 
     def _alltoall(self, _user, d_send, d_recv, bytes_per_peer):
         try:
@@ -262,6 +273,7 @@ class DistGroup:
             torch.cuda.synchronize()
             return 0
         except Exception:
+            self._abort_local()
             return 1
 
 

@@ -112,16 +112,27 @@ class Context:
             world = dist.get_world_size() if dist.is_initialized() else 1
             rank = dist.get_rank() if dist.is_initialized() else 0
         ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        status = 0
         if rank == 0:
-            self._check(self._lib.pm_comm_unique_id(ident))
+            status = int(self._lib.pm_comm_unique_id(ident))
         if world > 1:
+            # Rank 0 broadcasts (status, id) UNCONDITIONALLY and every rank checks the status afterwards: if the id could not
+            # be made, all ranks leave this function the same way, in step -- r04 raised on rank 0 before the broadcast and left
+            # the other ranks waiting in it.
             import torch
             import torch.distributed as dist
-            t = torch.tensor(list(bytes(ident)), dtype=torch.uint8)
+            t = torch.tensor([status & 0xff] + list(bytes(ident)), dtype=torch.uint8)
             if device is not None:
                 t = t.to(device)
             dist.broadcast(t, src=0)
-            ident = (C.c_uint8 * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
+            got = t.cpu().tolist()
+            if rank != 0:
+                status = -(256 - got[0]) if got[0] else 0          # the error codes are small negative numbers
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES)(*got[1:])
+        if status:
+            if rank == 0:
+                self._check(status)
+            raise Error(status, f"rank 0 could not create the communicator id (code {status})")
         self._check(self._lib.pm_comm_init(self._h, ident, rank, world))
         self.comm_world = world
 
