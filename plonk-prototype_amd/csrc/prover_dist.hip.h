@@ -195,9 +195,40 @@ static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uin
       p = fmul(p, omega4);
     }
   }
+  // What can fail on ONE rank only is done before the first exchange, so that the failure travels as the abort marker
+  // (ADVICE r04): the sigma indices of the slice (range, no repeats inside the slice; three power sums of the indices
+  // go round in the agreement below and must be those of a permutation of 0 .. 4n - 1) and the fixed-size allocations.
+  u64 sig_mom[3] = {0, 0, 0};
+  {
+    std::vector<uint8_t> seen((4 * n + 7) / 8, 0);
+    for (size_t p = 0; p < 4 * m; ++p) {
+      const int64_t q = sigma_index_slices[p];
+      if (q < 0 || (size_t)q >= 4 * n) return pm::set_err(ctx, PM_ERR_BAD_ARG, "sigma index outside the circuit");
+      if (seen[(size_t)q >> 3] & (1u << (q & 7))) return pm::set_err(ctx, PM_ERR_BAD_ARG, "sigma index repeated: not a permutation");
+      seen[(size_t)q >> 3] |= (uint8_t)(1u << (q & 7));
+      const u64 v = (u64)q;
+      sig_mom[0] += v;
+      sig_mom[1] += v * v;
+      sig_mom[2] += v * v * v;
+    }
+  }
+  struct Alloc { void** p; size_t elems; };
+  auto alloc_all = [&](const std::vector<Alloc>& list) -> int {
+    for (const Alloc& a : list) {
+      PK_TRY(pm_dev_alloc(ctx, a.elems * 32, a.p));
+      pk->device_bytes += a.elems * 32;
+    }
+    return PM_OK;
+  };
+  PK_TRY(alloc_all({{&pk->roots, m},        {&pk->x4, 4 * m},          {&pk->gs_pow, 4 * m},      {&pk->gs_inv_pow, 4 * m},
+                    {&pk->sel_coeffs, (size_t)NSEL * m},               {&pk->sigma_evals, 4 * m}, {&pk->sigma_coeffs, 4 * m},
+                    {&pk->sigma_coset, 16 * m}, {&pk->l1_coset, 4 * m}, {&pk->coeffs, 6 * m},      {&pk->num, m},
+                    {&pk->den, m},          {&pk->coset, 6 * (4 * m + 4)}, {&pk->t, 4 * m},        {&pk->tq, 4 * m},
+                    {&pk->r, m},            {&pk->agg, 2 * m},         {&pk->wit, 2 * m},         {&pk->pi_evals, m},
+                    {&pk->stage, 2 * m},    {&pk->tmp, 4 * m},         {&pk->scalar, 1}}));
   // trivial selector polynomials: a GLOBAL property (every rank must take the same branches): local flags, one exchange
   {
-    HFr flags[3] = {zero, zero, zero};   // words: [selector non-zero mask, q_arith differs from one, rank | world << 32 | n << 40]
+    HFr flags[2] = {zero, zero};   // words: [selector non-zero mask, q_arith differs from one, rank, n], [sigma index power sums]
     u64 nz = 0, not_one = selector_slices[Q_ARITH] ? 0 : 1;
     for (int s = 0; s < NSEL; ++s)
       if (selector_slices[s])
@@ -212,34 +243,47 @@ static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uin
     flags[0].l[1] = not_one;
     flags[0].l[2] = D.d.rank;
     flags[0].l[3] = (u64)n;
+    for (int k = 0; k < 3; ++k) flags[1].l[k] = sig_mom[k];
     std::vector<HFr> all;
-    PK_TRY(dist_scalars(ctx, D, flags, 1, all));
-    u64 nz_all = 0, not_one_all = 0, seen = 0;
+    PK_TRY(dist_scalars(ctx, D, flags, 2, all));
+    u64 nz_all = 0, not_one_all = 0, seen = 0, mom[3] = {0, 0, 0};
     for (uint32_t r = 0; r < D.d.world; ++r) {
-      nz_all |= all[r].l[0];
-      not_one_all |= all[r].l[1];
-      if (all[r].l[2] < 64) seen |= (u64)1 << all[r].l[2];
-      if (all[r].l[3] != (u64)n) return pm::set_err(ctx, PM_ERR_LENGTH, "the ranks disagree on the circuit size");
+      nz_all |= all[2 * r].l[0];
+      not_one_all |= all[2 * r].l[1];
+      if (all[2 * r].l[2] < 64) seen |= (u64)1 << all[2 * r].l[2];
+      if (all[2 * r].l[3] != (u64)n) return pm::set_err(ctx, PM_ERR_LENGTH, "the ranks disagree on the circuit size");
+      for (int k = 0; k < 3; ++k) mom[k] += all[2 * r + 1].l[k];
     }
     if (D.d.world <= 64 && seen != (D.d.world == 64 ? ~(u64)0 : (((u64)1 << D.d.world) - 1)))
       return pm::set_err(ctx, PM_ERR_BAD_ARG, "the ranks of the group are not 0 .. world - 1, each once");
+    // sum q^k over 0 .. 4n - 1 (mod 2^64): a configuration guard against slices that overlap or leave gaps between the
+    // ranks (inside a slice repeats were excluded above), not a proof that the union is a permutation
+    u64 want[3] = {0, 0, 0};
+    {
+      const unsigned __int128 N = (unsigned __int128)4 * n;   // 4n <= 2^28
+      const unsigned __int128 s1 = N * (N - 1) / 2;
+      want[0] = (u64)s1;
+      want[1] = (u64)((N - 1) * N * (2 * N - 1) / 6);
+      want[2] = (u64)(s1 * s1);
+    }
+    for (int k = 0; k < 3; ++k)
+      if (mom[k] != want[k]) return pm::set_err(ctx, PM_ERR_BAD_ARG, "the ranks' sigma indices are not a permutation of the 4n wire positions");
     for (int s = 0; s < NSEL; ++s) pk->sel_zero[s] = !((nz_all >> s) & 1);
     pk->arith_is_one = !not_one_all;
   }
-  struct Alloc { void** p; size_t elems; };
-  std::vector<Alloc> allocs = {{&pk->roots, m},        {&pk->x4, 4 * m},          {&pk->gs_pow, 4 * m},      {&pk->gs_inv_pow, 4 * m},
-                               {&pk->sel_coeffs, (size_t)NSEL * m},               {&pk->sigma_evals, 4 * m}, {&pk->sigma_coeffs, 4 * m},
-                               {&pk->sigma_coset, 16 * m}, {&pk->l1_coset, 4 * m}, {&pk->coeffs, 6 * m},      {&pk->num, m},
-                               {&pk->den, m},          {&pk->coset, 6 * (4 * m + 4)}, {&pk->t, 4 * m},        {&pk->tq, 4 * m},
-                               {&pk->r, m},            {&pk->agg, 2 * m},         {&pk->wit, 2 * m},         {&pk->pi_evals, m},
-                               {&pk->stage, 2 * m},    {&pk->tmp, 4 * m},         {&pk->scalar, 1}};
-  for (int s = 0; s < NSEL; ++s) {
-    const bool need = s <= Q_4 || (s == Q_ARITH ? !pk->arith_is_one : !pk->sel_zero[s]);
-    if (need) allocs.push_back({&pk->sel_coset[s], 4 * m});
-  }
-  for (const Alloc& a : allocs) {
-    PK_TRY(pm_dev_alloc(ctx, a.elems * 32, a.p));
-    pk->device_bytes += a.elems * 32;
+  {
+    // the allocations that depend on the flags, then the SECOND exchange: every rank says it holds everything it needs
+    // before anyone enters the first all-to-all (which carries no abort marker and has no timeout)
+    std::vector<Alloc> more;
+    for (int s = 0; s < NSEL; ++s) {
+      const bool need = s <= Q_4 || (s == Q_ARITH ? !pk->arith_is_one : !pk->sel_zero[s]);
+      if (need) more.push_back({&pk->sel_coset[s], 4 * m});
+    }
+    PK_TRY(alloc_all(more));
+    HFr ok = zero;
+    ok.l[0] = 0x6f6b;
+    std::vector<HFr> all;
+    PK_TRY(dist_scalars(ctx, D, &ok, 1, all));
   }
   // this rank's domain points, sub-coset powers g_s^i (i global) and the coset points x = g_s w^k in interleaved order
   PK_TRY(pm_fr_powers_dev(ctx, pk->omega.l, fpow64(pk->omega, lo).l, m, pk->roots, nullptr));
@@ -255,7 +299,11 @@ static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uin
     void* dst = at(pk->sel_coeffs, s * m);
     if (pk->sel_zero[s] || !selector_slices[s]) {
       PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, m, dst, nullptr));
-      if (pk->sel_zero[s]) continue;
+      if (pk->sel_zero[s]) {
+        // the zero polynomial on the coset: the quotient kernel reads this array (pm_dev_alloc does not clear)
+        if (pk->sel_coset[s]) PM_HIP(ctx, hipMemsetAsync(pk->sel_coset[s], 0, 4 * m * 32, ctx->stream));
+        continue;
+      }
     } else {
       PK_TRY(pm_dev_upload(ctx, dst, selector_slices[s], m * 32));
     }
@@ -275,8 +323,7 @@ static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uin
     const HFr ks[4] = {one, pk->k[0], pk->k[1], pk->k[2]};
     std::vector<u64> vals(16 * m);
     for (size_t p = 0; p < 4 * m; ++p) {
-      const int64_t q = sigma_index_slices[p];
-      if (q < 0 || (size_t)q >= 4 * n) return pm::set_err(ctx, PM_ERR_BAD_ARG, "sigma index outside the circuit");
+      const int64_t q = sigma_index_slices[p];   // checked above
       const size_t jj = (size_t)q / n, ii = (size_t)q % n;
       const HFr v = fmul(ks[jj], fmul(thi[ii >> h], tlo[ii & (nlo - 1)]));
       memcpy(&vals[4 * p], v.l, 32);
@@ -310,7 +357,7 @@ extern "C" int pm_plonk_preprocess_dist(pm_ctx* ctx, const pm_dist* dist, const 
   *out = nullptr;
   Dist D;
   D.d = *dist;
-  D.expect = 1;
+  D.expect = 2;
   int rc = dist_check(dist, n);
   if (rc) return rc;   // a malformed group or size is the same on every rank: nothing to tell the peers
   pm_dist_key* pk = new pm_dist_key();

@@ -23,11 +23,14 @@ from .host import Context, DeviceVector
 from .prover import Circuit
 
 
-def chain_circuit(n: int, seed: int = 1, public_rows=(0,)):
-    """-> (Circuit, witness [4, n, 4], public_inputs [n, 4]) for a power-of-two n >= 4; PI is non-zero on `public_rows`."""
+def chain_circuit(n: int, seed: int = 1, public_rows=(0,), zero_selectors=()):
+    """-> (Circuit, witness [4, n, 4], public_inputs [n, 4]) for a power-of-two n >= 4; PI is non-zero on `public_rows`;
+    the selectors named in `zero_selectors` (of q_m q_l q_r q_4 q_c) are identically zero."""
     rng = random.Random(seed)
     rnd = lambda: rng.getrandbits(256) % R_MOD   # noqa: E731
     q = {k: [rnd() for _ in range(n)] for k in ("q_m", "q_l", "q_r", "q_4", "q_c")}
+    for k in zero_selectors:
+        q[k] = [0] * n
     pi = [0] * n
     for r_ in public_rows:
         pi[r_] = rnd()

@@ -66,7 +66,7 @@ def test_dist_prover_equals_single_gpu(ctx, log_n, world, mixed):
         assert nbytes <= (160 * n // world + 6 * 4 + 1) * 32, (r, nbytes)
 
 
-@pytest.mark.parametrize("log_n,world", [(10, 4), (12, 2)])
+@pytest.mark.parametrize("log_n,world", [(10, 4), (12, 2), (12, 8)])
 def test_dist_prover_against_the_c_prover(oracle, log_n, world):
     """Not only "equal to the library's other prover": every commitment and evaluation of the distributed proof, and the
     verifier key, against the CPU prover composed from the C restatement (oracle/cpu_prover.py) with the same challenges --
@@ -93,6 +93,46 @@ def test_dist_prover_against_the_c_prover(oracle, log_n, world):
         finally:
             c.close()
     proof, vk = run_ranks(world, body)[world - 1]
+    replay = PR.derive_challenges(PR.Proof.from_bytes(proof.to_bytes()), vk, n, pub, t_eval=PR.fr_from_limbs(proof.evaluations["t"]))
+    assert all(replay[k] == v for k, v in proof.challenges.items())
+    cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
+    exp = CP.prove(oracle, cpk, srs, wit, pub, proof.challenges, threads=8)
+    for k, v in exp["evaluations"].items():
+        assert np.array_equal(proof.evaluations[k], v), k
+    for k, v in exp["commitments"].items():
+        assert np.array_equal(proof.commitments[k], v), k
+    for k, v in CP.verifier_key(oracle, cpk, srs, threads=8).items():
+        assert np.array_equal(vk[k], v), k
+
+
+def test_sharded_prover_world8_against_the_c_prover(oracle):
+    """The sharded prover's twin of the test above at the world size of the target machine: eight ranks,
+    2^12 gates (the configs[0] domain), pm_plonk_key_commit_sharded + pm_plonk_prove_sharded -- commitments, all 17
+    evaluations and the verifier key against oracle/cpu_prover.py, not against the library's own single-GPU proof."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import ShardedCommitKey, shard_range
+    from oracle import cpu_prover as CP
+    from oracle.cpu_oracle import ints_to_limbs
+    n, world = 1 << 12, 8
+    circuit, wit, pub = pa.synthetic.mixed_circuit(n, 212)
+    srs = oracle.g1_bases_arith(ints_to_limbs([0xA5A5], 4)[0], ints_to_limbs([0x7FFFFFFF], 4)[0], n, 8)
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            lo, hi = shard_range(n, r, world)
+            ckr = ShardedCommitKey(srs[lo:hi], lo, n, c, group=g, rank=r)
+            pkr = PR.preprocess(circuit, c, ckr)
+            proof = PR.prove(pkr, ckr, wit, pub)
+            vk = dict(pkr.verifier_key)
+            pkr.free()
+            return proof, vk
+        finally:
+            c.close()
+    res = run_ranks(world, body)
+    assert len({p.to_bytes() for p, _ in res}) == 1
+    proof, vk = res[5]
     replay = PR.derive_challenges(PR.Proof.from_bytes(proof.to_bytes()), vk, n, pub, t_eval=PR.fr_from_limbs(proof.evaluations["t"]))
     assert all(replay[k] == v for k, v in proof.challenges.items())
     cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
@@ -205,6 +245,88 @@ def test_dist_prover_failure_does_not_block(ctx):
     res = run_ranks(world, body)
     for r, codes in enumerate(res):
         assert codes == [-6 if r == 2 else -7, -6 if r == 1 else -7, 1040], (r, codes)
+
+
+@pytest.mark.parametrize("variant", ["q4_qc_zero", "q_arith_none"])
+def test_dist_prover_with_identically_zero_selectors(ctx, variant):
+    """a base selector that is zero on every rank -- or a q_arith that is absent -- has a coset array
+    the quotient kernel reads; it must hold zeros, not whatever the allocation held before.  A key with random selectors
+    is built and freed first on every rank's context so that the next key's allocations reuse dirty memory."""
+    import dataclasses
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    n, world = 1 << 10, 4
+    dirty, _, _, srs = _inputs(n, False, 3)
+    if variant == "q4_qc_zero":
+        circuit, wit, pi = pa.synthetic.chain_circuit(n, 19, zero_selectors=("q_4", "q_c"))
+    else:
+        circuit, wit, pi = pa.synthetic.chain_circuit(n, 23)
+        circuit = dataclasses.replace(circuit, q_arith=None)
+    ck = pa.CommitKey(srs, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
+    single = _blob(PR.prove(pk, ck, wit, pi), pk.verifier_key)
+    m = n // world
+
+    def body(r, g):
+        c = pa.Context(0)
+        try:
+            grp = DistGroup(rank=r, local=g)
+            PR.DistProverKey(dirty, c, grp).free()
+            key = PR.DistProverKey(circuit, c, grp)
+            bases = pa.host.Bases(c, srs[r * m:(r + 1) * m])
+            key.commit(bases)
+            out = _blob(key.prove(bases, wit, pi), key.verifier_key)
+            key.free()
+            return out
+        finally:
+            c.close()
+    for r, out in enumerate(run_ranks(world, body)):
+        assert out == single, r
+
+
+def test_dist_preprocess_failure_on_one_rank_does_not_block(ctx):
+    """a sigma index outside the circuit, or one repeated inside a slice, on ONE rank of four: that rank
+    gets PM_ERR_BAD_ARG before the first exchange, its peers PM_ERR_EXCHANGE from it, nobody reaches an all-to-all; slices
+    whose union is not a permutation (two ranks given the same rows) fail on every rank at the agreement."""
+    import dataclasses
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from plonk_prototype_amd.dist import DistGroup
+    n, world = 1 << 8, 4
+    circuit, wit, pi, srs = _inputs(n, False, 2)
+    m = n // world
+
+    def run(mutate):
+        def body(r, g):
+            c = pa.Context(0)
+            try:
+                sig = np.array(circuit.sigma_index, dtype=np.int64).reshape(4, n).copy()
+                mutate(r, sig)
+                try:
+                    PR.DistProverKey(dataclasses.replace(circuit, sigma_index=sig), c, DistGroup(rank=r, local=g)).free()
+                    return 0
+                except pa.Error as e:
+                    return e.code
+            finally:
+                c.close()
+        return run_ranks(world, body)
+
+    def outside(r, sig):
+        if r == 2:
+            sig[1, 2 * m + 5] = 4 * n
+    assert run(outside) == [-7, -7, -1, -7]
+
+    def repeated(r, sig):
+        if r == 1:
+            sig[0, m + 1] = sig[3, m + 7]
+    assert run(repeated) == [-7, -1, -7, -7]
+
+    def overlapping(r, sig):
+        if r == 3:
+            sig[:, 3 * m:4 * m] = sig[:, 2 * m:3 * m]      # rank 3 was given rank 2's rows
+    assert run(overlapping) == [-1, -1, -1, -1]
+    assert run(lambda r, sig: None) == [0, 0, 0, 0]
 
 
 def test_dist_rejects_bad_groups(ctx):
