@@ -32,6 +32,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel, grid=None, also=(), kinds=("pmc_summary", "pmc_prover_summary", "pmc_big_summary")):
+    """HBM bytes per launch of `kernel` from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of
+    MI355X_MICROARCH.md) -> (bytes, source) or (None, None).  The counters cannot be collected inside this process: the PMC
+    passes are separate `rocprofv3 --pmc` runs (tools/collect_pmc.sh -> tools/pmc_summary.py) whose summaries are committed under
+    profiles/; the newest round that has the kernel (at this grid, when given; every string of `also` in the entry's name) is quoted."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for rnd in ("r05", "r04"):
+        for kind in kinds:
+            path = os.path.join(root, f"{rnd}_{kind}.json")
+            try:
+                with open(path) as f_:
+                    ents = json.load(f_)
+            except (OSError, ValueError):
+                continue
+            hits = [(nm, e) for nm, e in ents.items()
+                    if kernel in nm and all(a in nm for a in also) and "hbm_bytes_per_launch_corrected" in e
+                    and (grid is None or f"grid={grid} " in nm + " ")]
+            if len(hits) == 1 or (hits and grid is not None):
+                nm, e = hits[0]
+                return int(e["hbm_bytes_per_launch_corrected"]), f"profiles/{rnd}_{kind}.json [{nm}]"
+    return None, None
+
+
+
 class stdout_to_stderr:
     """RCCL prints a version banner on STDOUT when a communicator is created; this script's stdout carries exactly
     one JSON line, so file descriptor 1 points at stderr while a communicator is being made."""
@@ -319,28 +343,20 @@ def main():
     # MI355X_MICROARCH.md) cannot be collected inside this process: the PMC passes are separate rocprofv3 runs of THIS
     # command (tools/collect_pmc.sh -> tools/pmc_summary.py).  When their summary for this round is in profiles/ and has
     # the dominant kernel at this size, its figure is quoted (with its source); otherwise null.
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_summary.json")
-    if os.path.exists(pmc_path):
-        # ntt_pass4_kernel<S, LT, OUT_UFAST, IN_WIDE, OUT_WIDE>: the first pass reads canonical and writes wide, the last the reverse
-        role_args = {"first": "false, true>", "last": "true, false>", "single": "false, false>", "middle": "true, true>"}
-        want = role_args[dom.rsplit("_", 1)[1]]
-        try:
-            with open(pmc_path) as f_:
-                for name_, ent_ in json.load(f_).items():
-                    if "ntt_pass" in name_ and want in name_ and f"grid={n // 4} " in name_ + " " \
-                            and "hbm_bytes_per_launch_corrected" in ent_:
-                        traffic, traffic_src = int(ent_["hbm_bytes_per_launch_corrected"]), f"profiles/r04_pmc_summary.json [{name_}]"
-        except (OSError, ValueError):
-            pass
+    # ntt_pass4_kernel<S, LT, OUT_UFAST, IN_WIDE, OUT_WIDE>: the first pass reads canonical and writes wide, the last the reverse
+    role_args = {"first": "false, true>", "last": "true, false>", "single": "false, false>", "middle": "true, true>"}
+    traffic, traffic_src = pmc_traffic("ntt_pass", n // 4, also=(role_args[dom.rsplit("_", 1)[1]],))
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(dom_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(algo_bytes),
                 "all_kernels_us": {s: round(v[1] / v[0] * 1e3, 2) for s, v in kern.items()},
                 "measured_in": f"a separate profiled loop of {prof_steps} steps ({dt_prof * 1e3:.4f} ms per step with an event "
                                f"pair around every kernel); `value` is from the loop with the timers off",
-                "pmc_evidence": "profiles/r04_pmc_summary.json (offline rocprofv3 --pmc passes of this command)",
-                "note": "integer-ALU bound (Fr Montgomery products); see DESIGN.md for the VALU ceiling"}
+                "pmc_evidence": "profiles/r0N_pmc_summary.json (offline rocprofv3 --pmc passes of this command, tools/collect_pmc.sh)",
+                "note": "integer-ALU bound (Fr products: DESIGN.md section 2 for the issue ceiling by opcode class).  A 2^20 pass is ONE "
+                        "round of 256 one-per-CU workgroups: its load (~8 us) and store (~9 us) do not overlap the arithmetic, so about "
+                        "a third of the launch is not arithmetic and an issue-ceiling fraction quoted for the pass is not a "
+                        "whole-kernel efficiency"}
 
     # ------------------------------------------------------------------ the one JSON line, and a safety net for N > 1
     # The headline above needs no data-path collective; the legs below do when N > 1 (the sharded MSM and prover through
@@ -433,11 +449,14 @@ def main():
             bpasses = pa.ntt_plan(kb)
             bs = bpasses[0] if bdom.endswith("first") else (bpasses[-1] if bdom.endswith("last") else bpasses[1])
             balgo = 64 * nb * bs / kb
+            big_role = {"first": "false, true>", "last": "true, false>", "middle": "true, true>"}[bdom.rsplit("_", 1)[1]]
+            big_traffic = pmc_traffic("ntt_pass", nb // 4, also=(big_role,), kinds=("pmc_big_summary",))
             big = {"log_n": kb, "ms_per_step": round(tb * 1e3, 3), "butterflies_per_s": nb * kb / tb,
                    "passes": bpasses,
                    "roofline": {"bound": "hbm", "kernel": bdom, "achieved": round(balgo / (bdom_ms * 1e-3) / 1e9, 2),
                                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(balgo / (bdom_ms * 1e-3) / HBM_PEAK, 4),
-                                "traffic": None, "avg_launch_us": round(bdom_ms * 1e3, 2),
+                                "traffic": big_traffic[0], "traffic_source": big_traffic[1],
+                                "avg_launch_us": round(bdom_ms * 1e3, 2),
                                 "algorithmic_bytes_per_launch": int(balgo),
                                 "all_kernels_us": {s_: round(v[1] / v[0] * 1e3, 2) for s_, v in bprof.items()},
                                 "whole_transform_frac": round(2 * 64 * nb / tb / HBM_PEAK, 4),
@@ -520,6 +539,10 @@ def main():
         dl = oracle.expected_dlog(full_sc, 0, ints_to_limbs([k0], 4)[0], ints_to_limbs([dd], 4)[0])
         ok = bool(np.array_equal(pa.g1_to_affine(res)[0], oracle.g1_mul(oracle.g1_generator(), dl)))
         acc_ms = mprof["msm_accumulate_l1"][1] / mprof["msm_accumulate_l1"][0]
+        # the summary of the pass that ran THIS shape: 2^20 with the table in pmc_summary, 2^24 in pmc_big_summary
+        msm_traffic = (None, None)
+        if table and world == 1 and mk in (20, 24):
+            msm_traffic = pmc_traffic("msm_accumulate_l1_kernel", kinds=("pmc_summary",) if mk == 20 else ("pmc_big_summary",))
         out = {"metric": "bls12_381_g1_msm_scalar_muls_per_s", "value": mn * steps / mdt,
                "unit": "scalar-muls/s", "points": mn, "ms_per_msm": mdt / steps * 1e3,
                "scaling": "strong" if world > 1 else None, "bit_exact_vs_oracle": ok,
@@ -528,7 +551,10 @@ def main():
                "roofline": {"bound": "hbm", "kernel": "msm_accumulate_l1",
                             "achieved": round(128 * (hi - lo) / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
                             "unit": "GB/s", "frac": round(128 * (hi - lo) / (acc_ms * 1e-3) / HBM_PEAK, 5),
-                            "traffic": None, "avg_launch_us": round(acc_ms * 1e3, 1),
+                            "traffic": msm_traffic[0], "traffic_source": msm_traffic[1],
+                            "traffic_note": "random 96-byte gathers from the window table: the x2 FETCH_SIZE correction is calibrated "
+                                            "for coalesced streams, the truth lies between half this figure and it (DESIGN.md section 4.2)",
+                            "avg_launch_us": round(acc_ms * 1e3, 1),
                             "algorithmic_bytes_per_launch": 128 * (hi - lo)}}
         if world > 1:
             # the exchange alone (2312-byte all-gather + fold), timed on every rank: max over ranks
@@ -806,6 +832,7 @@ def main():
             grp[key] += ms
         q_ms = pprof["plonk_quotient"][1] / pprof["plonk_quotient"][0]
         q_bytes = 19 * 32 * 4 * gn                      # 18 operands read + 1 result written per coset point
+        q_traffic = pmc_traffic("quotient_kernel", kinds=("pmc_prover_summary",)) if gk == 20 else (None, None)
         # two proofs in flight: a second context (own stream, own key and workspace) proving from a second host
         # thread over the same resident SRS -- one proof's NTT / quotient / opening phases and low-occupancy MSM
         # tails run under the other's accumulate kernels
@@ -837,19 +864,22 @@ def main():
             if all_ok(err is None):
                 barrier()
                 try:
+                    ctx.comm_stats(reset=True)
                     for _ in range(5):
                         t0 = time.perf_counter()
                         dkey.prove(ck._bases, d_wsl, pub_sparse)
                         d_times.append(time.perf_counter() - t0)
+                    dstats = {k_: v_ // 5 for k_, v_ in ctx.comm_stats().items()}
                 except Exception as e:                               # noqa: BLE001
                     err = f"timed proofs: {e}"
                 if all_ok(err is None):
                     barrier()
-                    dstats = dkey.exchange_stats() if hasattr(dkey, "exchange_stats") else None
                     dist_leg = {"ms_per_proof": round(max_over_ranks(float(np.median(d_times))) * 1e3, 2), "world": world,
                                 "equals_the_replicated_prover_byte_for_byte": dproof.to_bytes() == proof.to_bytes(),
                                 "device_bytes_per_rank": dkey.device_bytes, "preprocess_ms": round(t_dpre * 1e3, 1),
-                                "exchanges_per_proof": dstats,
+                                "exchanges_per_proof": dict(dstats, note="pm_comm_stats: transpose_steps = all-to-all CALLS a proof makes "
+                                                            "as soon as world > 1 (r04: 102), allgather_calls = 2312-byte message all-gathers; "
+                                                            "time over xGMI is NOT measured on one GPU"),
                                 "exchange": ("library RCCL communicator" if world > 1 and native_comm else
                                              f"torch.distributed ({backend})" if world > 1 else "none (one rank)"),
                                 "note": "pm_plonk_prove_dist: rows / coefficients [rank n / world, (rank + 1) n / world) of every vector per "
@@ -911,7 +941,8 @@ def main():
                   "quotient_roofline": {"bound": "hbm", "kernel": "plonk_quotient", "unit": "GB/s",
                                         "achieved": round(q_bytes / (q_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                         "frac": round(q_bytes / (q_ms * 1e-3) / HBM_PEAK, 4),
-                                        "algorithmic_bytes_per_launch": q_bytes, "traffic": None},
+                                        "algorithmic_bytes_per_launch": q_bytes, "traffic": q_traffic[0],
+                                        "traffic_source": q_traffic[1]},
                   "verifier_identity_holds": ident_ok, "commitment_matches_dlog": comm_ok,
                   "kzg_opening_equation_holds": kzg_ok, "srs_setup_ms": round(srs_ms, 1) if srs_ms else None,
                   "inputs": "witness resident in HBM; proving key, verifier key and SRS table resident"}

@@ -161,6 +161,22 @@ int pm_fr_ntt_dev(pm_ctx* ctx, const void* d_in, size_t in_len, size_t in_stride
 typedef int (*pm_alltoall_fn)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
 int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t log_n, uint32_t world,
                            uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user);
+/* The same for `batch` vectors in ONE sequence of exchanges (a prover round transforms 4 - 20 polynomials of one size: the
+ * all-to-all carries the batch's blocks together, so the number of exchange CALLS does not grow with the batch).
+ * d_inout: batch x N/world elements, vector v's block at element v N/world; d_stage: 2 x batch x N/world elements
+ * (1 x when world == 1).  d_halo (optional; forward + PM_NTT_TRANSPOSED only; NULL otherwise): batch x N2 elements, N2 =
+ * 2^(log_n - log_n / 2): vector v's copy of the FIRST ROW OF THE NEXT RANK's part of the block-transposed result (row 0 for the
+ * last rank), i.e. the values at index + 1 of this rank's last row -- what a consumer that reads X[k + 1] beside X[k] (the
+ * quotient's z(w X) and next-row wires) needs from its neighbour; it travels inside the second all-to-all as one more column
+ * per peer, no exchange of its own.  d_stage then holds 2 x batch x (N/world + N2) elements.
+ * pm_fr_ntt_fourstep_dev is this call with batch = 1 and no halo. */
+int pm_fr_ntt_fourstep_batch_dev(pm_ctx* ctx, void* d_inout, uint32_t batch, void* d_halo, void* d_stage, uint32_t log_n,
+                                 uint32_t world, uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user);
+/* Exchange counters of this context since the last reset: out[0] = all-to-all calls (one per transpose step with world > 1,
+ * whichever transport carried it), out[1] = bytes this rank sent in them, out[2] = fixed-size message all-gathers of the
+ * sharded / distributed prover, out[3] = transpose steps of the rank-split transforms whatever the world size (each is one
+ * all-to-all call as soon as world > 1).  What a multi-GPU deployment pays per proof, countable on one GPU. */
+int pm_comm_stats(pm_ctx* ctx, uint64_t out[4], int reset);
 
 /* ---- KZG commit: G1 MSM ---------------------------------------------------------------- */
 
@@ -380,13 +396,15 @@ int pm_plonk_proof_to_bytes(const pm_plonk_proof* proof, uint8_t out[PM_PLONK_PR
  * pm_plonk_prove_sharded splits only the MSMs: every rank still holds every polynomial and repeats every transform.
  * Here rank r of `world` (a power of two, world^2 <= n) owns rows / coefficients [r n / world, (r + 1) n / world) of
  * every vector and nothing else -- workspace / world, no replicated transform: the size-n transforms run as
- * pm_fr_ntt_fourstep_dev over the ranks (all-to-all), the 4n-coset work as four size-n sub-coset transforms, and prefix
- * product, openings and Ruffini division are local passes plus one all-gather of per-rank scalars each.  The proof and
- * the verifier key are bit-identical to pm_plonk_prove's on every rank.
+ * pm_fr_ntt_fourstep_batch_dev over the ranks (all the polynomials of a round in one sequence of all-to-alls), the 4n-coset
+ * work as four size-n sub-coset transforms whose results stay in the block-transposed order (the quotient is pointwise; its
+ * one next-row access reads the halo row the transform delivers), and prefix product, openings and Ruffini division are
+ * local passes plus one all-gather of per-rank scalars each: 12 all-to-all calls and 9 all-gathers per proof
+ * (pm_comm_stats).  The proof and the verifier key are bit-identical to pm_plonk_prove's on every rank.
  *   allgather: gathers ONE fixed-size message per rank (PM_COMM_MSG_WORDS u64 words, host memory; word 0 = a count,
  *              0 = the abort marker of a rank that gave up) into gathered[world][PM_COMM_MSG_WORDS]; returns 0 on success.
- *              NULL = the context's RCCL communicator (pm_comm_init).  10 per proof (the first an agreement on the
- *              arguments: public inputs, flags and size must be the same on every rank), 1 + 2 per key.
+ *              NULL = the context's RCCL communicator (pm_comm_init).  9 per proof (the first an agreement on the
+ *              arguments: public inputs, flags and size must be the same on every rank), 2 + 2 per key.
  *   alltoall:  the callback of pm_fr_ntt_fourstep_dev (device buffers); NULL = the communicator.
  * Inputs are the rank's slices: selector_slices[s] = m = n / world rows of selector s (NULL = identically zero on this
  * rank), sigma_index_slices = [4][m] (wire j of row rank m + i is followed by position sigma_index, a GLOBAL index
@@ -479,6 +497,10 @@ int pm_profile_read(pm_ctx* ctx, char* buf, size_t cap);
  * n elements. */
 int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                      size_t n);
+/* Pure host, no context: the host-side field arithmetic behind the MSM fold and the prover's challenge scalars
+ * (csrc/host_field.h).  op 0 = Fr product, 1 = Fp product, 2 = Fr inverse (binary extended Euclid), 3 = Fp inverse, 4 / 5 =
+ * the same inverses by exponentiation; Montgomery form in and out, n elements; b is ignored by the inversions. */
+int pm_test_host_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* Pure host, no device: the library's sizing pass for one MSM piece of this shape -- out[4] = {its return code, device
  * workspace bytes, pinned host bytes, (digit, point) pairs at most}. */
 int pm_test_msm_sizing(size_t n, uint32_t batch, long window_bits, uint32_t table_window_bits, uint32_t num_cus,

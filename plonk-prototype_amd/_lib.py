@@ -78,6 +78,10 @@ SIGNATURES = {
                                 C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pm_fr_ntt_fourstep_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pm_fr_ntt_fourstep_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pm_comm_stats": (C.c_int, [C.c_void_p, u64p, C.c_int]),
+    "pm_test_host_field_op": (C.c_int, [C.c_int, u64p, u64p, u64p, C.c_size_t]),
     "pm_g1_bases_upload": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pm_g1_bases_from_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pm_g1_fixed_base_mul_dev": (C.c_int, [C.c_void_p, u64p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,

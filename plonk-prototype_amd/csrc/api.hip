@@ -7,6 +7,7 @@
 #include "context.h"
 #include "field_inv.hip.h"
 #include "fields.hip.h"
+#include "host_field.h"
 
 namespace pm {
 
@@ -192,6 +193,7 @@ extern "C" void pm_shutdown(pm_ctx* ctx) {
   (void)hipDeviceSynchronize();
   release_caches(ctx, true);
   if (ctx->msm_host_pinned) (void)hipHostFree(ctx->msm_host_pinned);
+  if (ctx->poly_host_pinned) (void)hipHostFree(ctx->poly_host_pinned);
   if (ctx->msm_side) (void)hipStreamDestroy(ctx->msm_side);
   for (hipEvent_t e : ctx->msm_events) (void)hipEventDestroy(e);
   for (StreamOrder* o : {&ctx->ord_ntt, &ctx->ord_msm, &ctx->ord_poly})
@@ -318,6 +320,30 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     return PM_OK;
   }
   return set_err(ctx, PM_ERR_BAD_ARG, std::string("unknown option ") + key);
+}
+
+// Pure host, no context: the host-side field arithmetic behind the MSM fold and the prover's challenge scalars
+// (host_field.h).  op 0 = Fr product, 1 = Fp product, 2 = Fr inverse (binary extended Euclid), 3 = Fp inverse, 4 / 5 = the
+// same inverses by exponentiation (the independent check); Montgomery form in and out; b is ignored by the inversions.
+extern "C" int pm_test_host_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!a || !out || op < 0 || op > 5 || (op < 2 && !b)) return PM_ERR_BAD_ARG;
+  using namespace pm::host;
+  for (size_t i = 0; i < n; ++i) {
+    if (op == 0 || op == 2 || op == 4) {
+      HFr x, y;
+      memcpy(x.l, a + 4 * i, 32);
+      if (op == 0) memcpy(y.l, b + 4 * i, 32);
+      const HFr r = op == 0 ? mul(x, y, FR()) : (op == 2 ? inv(x, FR()) : inv_fermat(x, FR()));
+      memcpy(out + 4 * i, r.l, 32);
+    } else {
+      HFp x, y;
+      memcpy(x.l, a + 6 * i, 48);
+      if (op == 1) memcpy(y.l, b + 6 * i, 48);
+      const HFp r = op == 1 ? mul(x, y, FP()) : (op == 3 ? inv(x, FP()) : inv_fermat(x, FP()));
+      memcpy(out + 6 * i, r.l, 48);
+    }
+  }
+  return PM_OK;
 }
 
 extern "C" int pm_test_field_op(pm_ctx* ctx, int op, const uint64_t* a, const uint64_t* b,

@@ -59,6 +59,7 @@ struct pm_ctx {
   pm::DeviceBuffer ntt_tmp[2];
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
   pm::StreamOrder ord_ntt, ord_msm, ord_poly;           // cross-stream ordering of the shared scratch + tables
+  unsigned long long stat_alltoall_calls = 0, stat_alltoall_bytes = 0, stat_allgather_calls = 0, stat_transpose_steps = 0;   // pm_comm_stats
   int calls_holding_tables = 0;                         // calls that keep table pointers across unlocked sections (four-step NTT): pm_trim refuses
   // MSM workspaces
   pm::DeviceBuffer msm_ws;
@@ -70,6 +71,7 @@ struct pm_ctx {
   pm::DeviceBuffer poly_ws;                             // scratch of the polynomial helpers
   pm::DeviceBuffer poly_tab;                            // power tables of pm_fr_poly_ruffini_dev
   void* msm_host_pinned = nullptr;
+  void* poly_host_pinned = nullptr;                     // 2 x PM_LINCOMB_MAX results of the evaluation batches (poly.hip)
   size_t msm_host_pinned_bytes = 0;
   // multi-GPU exchange (comm.hip): RCCL communicator of this rank, device and pinned staging buffers
   void* comm = nullptr;
@@ -138,6 +140,20 @@ int fold_gathered(const uint64_t* msgs, int world, uint32_t k_local, uint64_t* o
 // quotient kernel over `rows` rows of the coset (4 rows points); halo: the arrays read at index + 4 (z, wires 0 1 3)
 // carry four more points after the last row instead of wrapping around (plonk_rounds.hip)
 int plonk_quotient_rows(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t rows, bool halo, void* d_out, void* hip_stream);
+// planar layout of the distributed prover (plonk_rounds.hip, struct QuotLayout): four planes [s][rows] per array in the
+// block-transposed order of the rank-split transform, halo rows [4][n2] for a, b, d (halo_w[0], [1], [3]) and z
+struct QuotPlanar {
+  uint32_t n2, rot;
+  const void* halo_w[4];
+  const void* halo_z;
+};
+int plonk_quotient_layout(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t rows, bool halo, const QuotPlanar* planar,
+                          void* d_out, void* hip_stream);
+int poly_evaluate_two(pm_ctx* ctx, uint32_t k1, const void* const* polys1, const uint64_t point1[4], uint64_t* out1, uint32_t k2,
+                      const void* const* polys2, const uint64_t point2[4], uint64_t* out2, size_t n);   // poly.hip
+int coset_expand(pm_ctx* ctx, const void* const* d_src, uint32_t count, const void* d_gs_pow, size_t m, void* d_out);
+int sigma_evals_from_index(pm_ctx* ctx, const int64_t* idx, size_t count, uint32_t log_n, const uint64_t omega[4],
+                           const uint64_t k[3][4], void* d_out);
 struct OrderScope {
   pm_ctx* ctx;
   StreamOrder& o;

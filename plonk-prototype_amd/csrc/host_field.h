@@ -87,35 +87,40 @@ inline El<N> sub(const El<N>& a, const El<N>& b, const Field<N>& F) {
   if (sub_n<N>(r.l, a.l, b.l)) add_n<N>(r.l, r.l, F.m);
   return r;
 }
-// separated operand scanning: full 2N-limb product, then N reduction rounds
+// coarsely integrated operand scanning (CIOS): one pass per limb of b -- multiply-accumulate, then one reduction round;
+// N + 2 words of state, every loop bound a template constant (fully unrolled by the compiler)
 template <int N>
 inline El<N> mul(const El<N>& a, const El<N>& b, const Field<N>& F) {
-  u64 t[2 * N + 1];
-  memset(t, 0, sizeof t);
+  u64 t[N + 2] = {0};
+#pragma GCC unroll 8
   for (int i = 0; i < N; ++i) {
     u64 c = 0;
+    const u64 bi = b.l[i];
+#pragma GCC unroll 8
     for (int j = 0; j < N; ++j) {
-      u128 p = (u128)a.l[i] * b.l[j] + t[i + j] + c;
-      t[i + j] = (u64)p;
+      u128 p = (u128)a.l[j] * bi + t[j] + c;
+      t[j] = (u64)p;
       c = (u64)(p >> 64);
     }
-    t[i + N] = c;
-  }
-  u64 top = 0;
-  for (int i = 0; i < N; ++i) {
-    u64 q = t[i] * F.inv, c = 0;
-    for (int j = 0; j < N; ++j) {
-      u128 p = (u128)q * F.m[j] + t[i + j] + c;
-      t[i + j] = (u64)p;
+    u128 s = (u128)t[N] + c;
+    t[N] = (u64)s;
+    t[N + 1] = (u64)(s >> 64);
+    const u64 q = t[0] * F.inv;
+    u128 p0 = (u128)q * F.m[0] + t[0];
+    c = (u64)(p0 >> 64);
+#pragma GCC unroll 8
+    for (int j = 1; j < N; ++j) {
+      u128 p = (u128)q * F.m[j] + t[j] + c;
+      t[j - 1] = (u64)p;
       c = (u64)(p >> 64);
     }
-    u128 s = (u128)t[i + N] + c + top;
-    t[i + N] = (u64)s;
-    top = (u64)(s >> 64);
+    s = (u128)t[N] + c;
+    t[N - 1] = (u64)s;
+    t[N] = t[N + 1] + (u64)(s >> 64);
   }
   El<N> r;
-  memcpy(r.l, t + N, 8 * N);
-  if (top || geq<N>(r.l, F.m)) sub_n<N>(r.l, r.l, F.m);
+  memcpy(r.l, t, 8 * N);
+  if (t[N] || geq<N>(r.l, F.m)) sub_n<N>(r.l, r.l, F.m);
   return r;
 }
 template <int N>
@@ -157,8 +162,64 @@ inline El<N> pow(const El<N>& a, const u64* e, int elimbs, const Field<N>& F) {
   }
   return acc;
 }
+// x / 2 mod m for odd m: (x + m) / 2 when x is odd (the carry of the sum is the top bit)
+template <int N>
+inline void half_mod(u64* x, const u64* m) {
+  u64 top = 0;
+  if (x[0] & 1) top = add_n<N>(x, x, m);
+  for (int i = 0; i < N - 1; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 63);
+  x[N - 1] = (x[N - 1] >> 1) | (top << 63);
+}
+template <int N>
+inline void shr1(u64* x) {
+  for (int i = 0; i < N - 1; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 63);
+  x[N - 1] >>= 1;
+}
+template <int N>
+inline bool is_one(const u64* x) {
+  u64 r = x[0] ^ 1;
+  for (int i = 1; i < N; ++i) r |= x[i];
+  return r == 0;
+}
+// 1 / a in the field (Montgomery form in and out; 0 -> 0) by the binary extended Euclid on plain integers (HAC 14.61's
+// shape: a few hundred shift / subtract steps on N limbs, ~4 us for Fp) instead of a^(m - 2) (575 products, ~40 us -- it
+// was the longest single piece of host work behind every commitment batch of a small proof).  The representative a R is
+// inverted as an integer, (a R)^-1 = a^-1 R^-1, and two products by R^2 bring it back: a^-1 R.  Checked against the
+// exponentiation in tests/test_abi.py (pm_test_host_inverse).
 template <int N>
 inline El<N> inv(const El<N>& a, const Field<N>& F) {
+  if (is_zero(a)) return a;
+  u64 u[N], v[N], x1[N], x2[N];
+  memcpy(u, a.l, sizeof u);
+  memcpy(v, F.m, sizeof v);
+  memset(x1, 0, sizeof x1);
+  memset(x2, 0, sizeof x2);
+  x1[0] = 1;
+  while (!is_one<N>(u) && !is_one<N>(v)) {
+    while (!(u[0] & 1)) {
+      shr1<N>(u);
+      half_mod<N>(x1, F.m);
+    }
+    while (!(v[0] & 1)) {
+      shr1<N>(v);
+      half_mod<N>(x2, F.m);
+    }
+    if (geq<N>(u, v)) {
+      sub_n<N>(u, u, v);
+      if (sub_n<N>(x1, x1, x2)) add_n<N>(x1, x1, F.m);
+    } else {
+      sub_n<N>(v, v, u);
+      if (sub_n<N>(x2, x2, x1)) add_n<N>(x2, x2, F.m);
+    }
+  }
+  El<N> y, r2;
+  memcpy(y.l, is_one<N>(u) ? x1 : x2, sizeof y.l);
+  memcpy(r2.l, F.r2, sizeof r2.l);
+  return mul<N>(mul<N>(y, r2, F), r2, F);
+}
+// the same by exponentiation (kept as the independent check of inv)
+template <int N>
+inline El<N> inv_fermat(const El<N>& a, const Field<N>& F) {
   u64 e[N], two[N];
   memset(two, 0, sizeof two);
   two[0] = 2;

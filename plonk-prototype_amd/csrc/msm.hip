@@ -1225,7 +1225,9 @@ extern "C" int pm_g1_bases_precompute(pm_ctx* ctx, pm_bases* bases, uint32_t win
   // 20 -> 15): a top window of 1-4 bits (c = 17, 18, 21) puts n / 8 points into each of a few buckets.
   // 2^24 (profiles/r03_msm_sweep.txt): c = 22 -- 12 table rows instead of 13, 2^21 buckets -- 36.6 ms against 38.9 ms
   // for c = 20 and 37.7 ms for c = 24 (whose 2^23 buckets cost 4.3 ms to reduce).
-  const u32 c = window_bits ? window_bits : (lg <= 15 ? 13u : (lg <= 18 ? 16u : (lg <= 22 ? 20u : 22u)));
+  // measured per size with the r04 bucket reduction (profiles/r05_small_msm.txt): 13 up to 2^13 points, 16 from 2^14 (r02 - r04:
+  // from 2^16; a 2^14-gate proof 3.05 -> 2.81 ms), 20 from 2^19, 22 from 2^23
+  const u32 c = window_bits ? window_bits : (lg <= 13 ? 13u : (lg <= 18 ? 16u : (lg <= 22 ? 20u : 22u)));
   if (c < 8 || c > 24) return set_err(ctx, PM_ERR_BAD_ARG, "window_bits must be 8..24");
   if (n == 0) return PM_OK;
   const u32 nwin = (256 + c - 1) / c;

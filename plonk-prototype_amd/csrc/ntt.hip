@@ -782,9 +782,16 @@ PM_DEV void fs_apply(u32x4& v0, u32x4& v1, const FsMul& m, u32 a, u32 b, u32 C) 
   v0 = raw[0];
   v1 = raw[1];
 }
-// send[(s * Cw + bl) * R_loc + a] = f(src[a * C + s * Cw + bl]),  s = b / Cw, bl = b % Cw
-__global__ void __launch_bounds__(256) fs_pack_kernel(const u32x4* src, u32 R_loc, u32 C, u32 Cw, u32x4* send, const FsMul m) {
+// A transpose step works on `batch` vectors at once: the per-peer block of the all-to-all holds the batch's blocks one
+// after the other, so ONE exchange carries all of them (message size x batch, call count / batch).
+// send[((s * batch + v) * Cs + bl) * R_loc + a] = f(src_v[a * C + s * Cw + bl]),  s = b / Cw, bl = b % Cw;  Cs = Cw, or Cw + 1
+// with `halo`: the block for rank s then ends with one more column, (s + 1) Cw mod C -- the first column of the NEXT
+// rank's range (the last rank gets column 0) -- which the unpack turns into one extra row.
+__global__ void __launch_bounds__(256) fs_pack_kernel(const u32x4* src, size_t src_stride, u32 batch, u32 R_loc, u32 C, u32 Cw,
+                                                      u32 halo, u32x4* send, const FsMul m) {
   __shared__ u32x4 t0[32][33], t1[32][33];
+  const u32 v = blockIdx.z;
+  src += 2 * (size_t)v * src_stride;
   const u32 a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
   const u32 tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;   // 32 x 8
   for (u32 r = ty; r < 32; r += 8) {
@@ -797,34 +804,46 @@ __global__ void __launch_bounds__(256) fs_pack_kernel(const u32x4* src, u32 R_lo
     }
   }
   __syncthreads();
+  const u32 Cs = Cw + halo, W = C / Cw;
   for (u32 r = ty; r < 32; r += 8) {
     const u32 b = b0 + r, a = a0 + tx;
     if (a < R_loc && b < C) {
       const u32 s = b / Cw, bl = b % Cw;
-      const size_t o = ((size_t)s * Cw + bl) * R_loc + a;
+      const size_t o = (((size_t)s * batch + v) * Cs + bl) * R_loc + a;
       send[2 * o] = t0[tx][r];
       send[2 * o + 1] = t1[tx][r];
+      if (halo && bl == 0) {   // also the extra column of the rank before s
+        const u32 sp = (s + W - 1) % W;
+        const size_t oh = (((size_t)sp * batch + v) * Cs + Cw) * R_loc + a;
+        send[2 * oh] = t0[tx][r];
+        send[2 * oh + 1] = t1[tx][r];
+      }
     }
   }
 }
-// dst[bl * R + p * R_loc + a] = g(recv[(p * Cw + bl) * R_loc + a]),  R = W R_loc; g's index: row bl, column p R_loc + a
-__global__ void __launch_bounds__(256) fs_unpack_kernel(const u32x4* recv, u32 R_loc, u32 W, u32 Cw, u32x4* dst, const FsMul m) {
+// dst_v[bl * R + p * R_loc + a] = g(recv[((p * batch + v) * Cs + bl) * R_loc + a]),  R = W R_loc; g's index: row bl, column
+// p R_loc + a.  With halo the extra row bl == Cw goes to halo_v[p * R_loc + a] instead.
+__global__ void __launch_bounds__(256) fs_unpack_kernel(const u32x4* recv, u32 batch, u32 R_loc, u32 W, u32 Cw, u32 halo,
+                                                        u32x4* dst, size_t dst_stride, u32x4* halo_dst, const FsMul m) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 R = R_loc * W;
-  if (t >= (size_t)Cw * R) return;
+  const u32 v = blockIdx.y;
+  const u32 R = R_loc * W, Cs = Cw + halo;
+  if (t >= (size_t)Cs * R) return;
   const u32 bl = (u32)(t / R), rr = (u32)(t % R), p = rr / R_loc, a = rr % R_loc;
-  const size_t i = ((size_t)p * Cw + bl) * R_loc + a;
+  const size_t i = (((size_t)p * batch + v) * Cs + bl) * R_loc + a;
   u32x4 v0 = recv[2 * i], v1 = recv[2 * i + 1];
   fs_apply(v0, v1, m, bl, rr, R);
-  dst[2 * t] = v0;
-  dst[2 * t + 1] = v1;
+  u32x4* o = bl < Cw ? dst + 2 * ((size_t)v * dst_stride + t) : halo_dst + 2 * ((size_t)v * R + rr);
+  o[0] = v0;
+  o[1] = v1;
 }
 
 }  // namespace pm
 
-extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t log_n, uint32_t world,
-                                      uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user) {
-  if (!ctx || !d_inout || !d_stage) return PM_ERR_BAD_ARG;
+extern "C" int pm_fr_ntt_fourstep_batch_dev(pm_ctx* ctx, void* d_inout, uint32_t batch, void* d_halo, void* d_stage,
+                                            uint32_t log_n, uint32_t world, uint32_t rank, uint32_t flags,
+                                            pm_alltoall_fn exchange, void* user) {
+  if (!ctx || !d_inout || !d_stage || batch == 0) return PM_ERR_BAD_ARG;
   if (world == 0 || (world & (world - 1)) || rank >= world) return PM_ERR_BAD_ARG;
   if (flags & ~(PM_NTT_INVERSE | PM_NTT_COSET | PM_NTT_TRANSPOSED)) return PM_ERR_BAD_ARG;
   if (log_n < 2 || log_n > 26) return PM_ERR_DOMAIN_TOO_LARGE;   // 32-bit exponents of the two-level tables
@@ -832,10 +851,15 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
   const uint32_t n1 = 1u << l1, n2 = 1u << l2;
   if (n1 % world || n2 % world) return PM_ERR_BAD_ARG;            // the ranks must divide both factors
   const bool inverse = flags & PM_NTT_INVERSE, coset = flags & PM_NTT_COSET;
-  const size_t blk = ((size_t)1 << log_n) / world;                // elements per rank
+  const bool want_halo = d_halo != nullptr;
+  if (want_halo && (inverse || !(flags & PM_NTT_TRANSPOSED))) return PM_ERR_BAD_ARG;   // a row of the block-transposed result
+  const size_t blk = ((size_t)1 << log_n) / world;                // elements per rank and vector
+  if (batch > 65535u) return PM_ERR_BAD_ARG;
   u32x4* x = (u32x4*)d_inout;
   u32x4* send = (u32x4*)d_stage;
-  u32x4* recv = world == 1 ? send : send + 2 * blk;
+  // stage: [send | recv], each batch x (blk, or blk + n2 with a halo row) elements; one rank needs no recv half
+  const size_t stage_half = (size_t)batch * (blk + (want_halo ? n2 : 0));
+  u32x4* recv = world == 1 ? send : send + 2 * stage_half;
   hipStream_t st;
   NttDomainTables* dt = nullptr;
   // the transform holds the NTT resource group from here to its last launch, with the context unlocked in between (the
@@ -863,24 +887,31 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
     if (rc) return rc;
   }
   const FsMul none{0, nullptr, nullptr, 0, 0};
-  // one transpose: slice [R_loc][C] of a row-distributed [R][C] matrix -> slice [C / W][R] of its transpose.  The
-  // result is in *where: x -- or, with one rank and no factor on the way in, the stage buffer itself (the unpack
-  // would be a plain copy: the next sub-transform reads it from there; `keep_in_x` forces the copy)
+  // one transpose of every vector of the batch: slice [R_loc][C] of a row-distributed [R][C] matrix -> slice [C / W][R]
+  // of its transpose (+ one halo row).  The result is in *where: x -- or, with one rank and no factor on the way in, the
+  // stage buffer itself (the unpack would be a plain copy: the next sub-transform reads it from there; `keep_in_x`
+  // forces the copy)
   auto transpose = [&](const u32x4* from, u32 R_loc, u32 C, const FsMul& on_pack, const FsMul& on_unpack, bool keep_in_x,
-                       const u32x4** where) -> int {
-    const u32 Cw = C / world;
+                       bool halo, const u32x4** where) -> int {
+    const u32 Cw = C / world, Cs = Cw + (halo ? 1u : 0u);
+    const size_t peer_bytes = (size_t)batch * Cs * R_loc * 32;
     {
       std::lock_guard<std::mutex> lk(ctx->mu);
       ProfScope prof(ctx, st, "ntt_fourstep_transpose");
-      hipLaunchKernelGGL(fs_pack_kernel, dim3((C + 31) / 32, (R_loc + 31) / 32), dim3(256), 0, st, from, R_loc, C, Cw,
-                         send, on_pack);
+      hipLaunchKernelGGL(fs_pack_kernel, dim3((C + 31) / 32, (R_loc + 31) / 32, batch), dim3(256), 0, st, from, blk, batch, R_loc,
+                         C, Cw, halo ? 1u : 0u, send, on_pack);
       PM_HIP(ctx, hipGetLastError());
+      ++ctx->stat_transpose_steps;
+      if (world > 1) {
+        ++ctx->stat_alltoall_calls;
+        ctx->stat_alltoall_bytes += peer_bytes * (world - 1);
+      }
       if (world > 1 && !exchange) {
-        int rc = comm_alltoall(ctx, send, recv, (size_t)Cw * R_loc * 32, st);
+        int rc = comm_alltoall(ctx, send, recv, peer_bytes, st);
         if (rc) return rc;
       }
     }
-    if (world == 1 && on_unpack.mode == 0 && !keep_in_x) {
+    if (world == 1 && on_unpack.mode == 0 && !keep_in_x && !halo) {
       *where = send;
       return PM_OK;
     }
@@ -889,13 +920,13 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
         std::lock_guard<std::mutex> lk(ctx->mu);
         PM_HIP(ctx, hipStreamSynchronize(st));
       }
-      if (exchange(user, send, recv, (size_t)Cw * R_loc * 32) != 0) return set_err(ctx, PM_ERR_EXCHANGE, "the all-to-all callback failed");
+      if (exchange(user, send, recv, peer_bytes) != 0) return set_err(ctx, PM_ERR_EXCHANGE, "the all-to-all callback failed");
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     ProfScope prof(ctx, st, "ntt_fourstep_transpose");
-    const size_t total = (size_t)Cw * R_loc * world;
-    hipLaunchKernelGGL(fs_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const u32x4*)recv, R_loc, world,
-                       Cw, x, on_unpack);
+    const size_t total = (size_t)Cs * R_loc * world;
+    hipLaunchKernelGGL(fs_unpack_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, st, (const u32x4*)recv, batch,
+                       R_loc, world, Cw, halo ? 1u : 0u, x, blk, (u32x4*)d_halo, on_unpack);
     PM_HIP(ctx, hipGetLastError());
     *where = x;
     return PM_OK;
@@ -914,22 +945,44 @@ extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage,
     // 1: [A/W][B] -> [B/W][A]  (coset_fft: x[n] *= g^n on the way out)
     FsMul pre = none;
     if (coset && !inverse) pre = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (na / world)};
-    rc = transpose(x, na / world, nb, pre, none, false, &cur);
+    rc = transpose(x, na / world, nb, pre, none, false, false, &cur);
     if (rc) return rc;
   }
-  // 2: B/W transforms of size A over the columns
-  rc = pm_fr_ntt_dev(ctx, cur, na, na, x, na, la, nb / world, sub, nullptr);
+  // 2: B/W transforms of size A over the columns, every vector of the batch (the blocks are contiguous: one call)
+  rc = pm_fr_ntt_dev(ctx, cur, na, na, x, na, la, batch * (nb / world), sub, nullptr);
   if (rc) return rc;
-  // 3: [B/W][A] -> [A/W][B], element (j, k1) times w^(j k1) on the way out
+  // 3: [B/W][A] -> [A/W][B], element (j, k1) times w^(j k1) on the way out; with a halo one more row: the next rank's first
   const FsMul tw{1, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, rank * (nb / world)};
-  rc = transpose(x, nb / world, na, tw, none, false, &cur);
+  rc = transpose(x, nb / world, na, tw, none, false, want_halo, &cur);
   if (rc) return rc;
-  // 4: A/W transforms of size B over the rows
-  rc = pm_fr_ntt_dev(ctx, cur, nb, nb, x, nb, lb, na / world, sub, nullptr);
+  // 4: A/W transforms of size B over the rows (and over the halo rows: one per vector, contiguous in d_halo)
+  rc = pm_fr_ntt_dev(ctx, cur, nb, nb, x, nb, lb, batch * (na / world), sub, nullptr);
   if (rc) return rc;
+  if (want_halo) {
+    rc = pm_fr_ntt_dev(ctx, d_halo, nb, nb, d_halo, nb, lb, batch, sub, nullptr);
+    if (rc) return rc;
+  }
   if (transposed && !inverse) return PM_OK;
   // 5: [A/W][B] (k1, k2) -> [B/W][A] (k2, k1) = natural order  (coset_ifft: X[k] *= g^-k on the way in)
   FsMul post = none;
   if (coset && inverse) post = FsMul{2, (const u32x4*)dt->cs_hi, (const u32x4*)dt->cs_lo, dt->lh, rank * (nb / world)};
-  return transpose(x, na / world, nb, none, post, true, &cur);
+  return transpose(x, na / world, nb, none, post, true, false, &cur);
+}
+
+extern "C" int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t log_n, uint32_t world,
+                                      uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user) {
+  return pm_fr_ntt_fourstep_batch_dev(ctx, d_inout, 1, nullptr, d_stage, log_n, world, rank, flags, exchange, user);
+}
+
+extern "C" int pm_comm_stats(pm_ctx* ctx, uint64_t out[4], int reset) {
+  if (!ctx) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (out) {
+    out[0] = ctx->stat_alltoall_calls;
+    out[1] = ctx->stat_alltoall_bytes;
+    out[2] = ctx->stat_allgather_calls;
+    out[3] = ctx->stat_transpose_steps;
+  }
+  if (reset) ctx->stat_alltoall_calls = ctx->stat_alltoall_bytes = ctx->stat_allgather_calls = ctx->stat_transpose_steps = 0;
+  return PM_OK;
 }

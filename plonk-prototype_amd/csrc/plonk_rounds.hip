@@ -152,9 +152,20 @@ PM_DEV Fr wdelta(const Fr& f, const WidgetConsts& c) {
   return wmul(fe_add<FrP>(u, fr_limbs(c.c2)), u);          // first operand unreduced: limbs < 2^30 + ., value < 2.02 r
 }
 
-template <bool WIDGETS>
+// Where the 4 m coset points of a launch sit.  Interleaved (one GPU, pm_plonk_quotient_dev): point 4 k + s = g w4^s w^k, the same
+// polynomial at w X is index + 4 (wrapping at `wrap`).  PLANAR (the distributed prover, prover_dist.hip.h): four planes [s][m],
+// plane s = the rank's rows of sub-coset g w4^s H in the block-transposed order of pm_fr_ntt_fourstep_batch_dev (position
+// k1_local N2 + k2 holds k = k2 N1 + k1), so w X is index + N2 -- one row down -- and the row below the rank's last one
+// is the halo row the transform delivered with it (four planes of N2 per polynomial; for the last rank it is rank 0's first
+// row, where k + 1 means k2 + 1: `rot`).
+struct QuotLayout {
+  u32 log_m, n2, rot;
+  const u32x4* halo_w[4];   // a, b, (unused), d
+  const u32x4* halo_z;
+};
+template <bool WIDGETS, bool PLANAR>
 __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, const RoundConsts kc, const WidgetConsts wc,
-                                                       size_t n4, size_t wrap) {
+                                                       size_t n4, size_t wrap, const QuotLayout L) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;   // a multiple of 4: i mod 4 is fixed per thread
   const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 r4 = (u32)(t0 & 3);
@@ -164,7 +175,16 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
     zhi.l[l] = r4 == 0 ? kc.zh_inv[0][l] : (r4 == 1 ? kc.zh_inv[1][l] : (r4 == 2 ? kc.zh_inv[2][l] : kc.zh_inv[3][l]));
   const Fr gamma = fr_limbs(kc.gamma);
   for (size_t i = t0; i < n4; i += stride) {
-    const size_t inext = i + 4 < wrap ? i + 4 : i + 4 - wrap;   // wrap = n4, or n4 + 4 when the rows carry a halo
+    size_t inext = i + 4 < wrap ? i + 4 : i + 4 - wrap;   // wrap = n4, or n4 + 4 when the rows carry a halo
+    bool in_halo = false;
+    if (PLANAR) {
+      const u32 sp = (u32)(i >> L.log_m), pos = (u32)(i & (((size_t)1 << L.log_m) - 1)), m_ = 1u << L.log_m;
+#pragma unroll
+      for (int l = 0; l < 9; ++l)
+        zhi.l[l] = sp == 0 ? kc.zh_inv[0][l] : (sp == 1 ? kc.zh_inv[1][l] : (sp == 2 ? kc.zh_inv[2][l] : kc.zh_inv[3][l]));
+      in_halo = pos + L.n2 >= m_;
+      inext = in_halo ? (size_t)sp * L.n2 + ((pos + L.n2 - m_ + L.rot) & (L.n2 - 1)) : i + L.n2;
+    }
     Fr w[4], f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = to_dev(ld_canon(p.w[j], i));
@@ -179,8 +199,9 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
     if (WIDGETS) {
       // the rows' other gate kinds; "next" = the same polynomial at w X = index + 4 on the 4n coset
       const Fr a = w[0], b = w[1], c = w[2], d = w[3];
-      const Fr an = to_dev(ld_canon(p.w[0], inext)), bn = to_dev(ld_canon(p.w[1], inext)),
-               dn = to_dev(ld_canon(p.w[3], inext));
+      const Fr an = to_dev(ld_canon(PLANAR && in_halo ? L.halo_w[0] : p.w[0], inext)),
+               bn = to_dev(ld_canon(PLANAR && in_halo ? L.halo_w[1] : p.w[1], inext)),
+               dn = to_dev(ld_canon(PLANAR && in_halo ? L.halo_w[3] : p.w[3], inext));
       Fr wsum = fe_zero<FrP>();
       if (p.q_range) {
         Fr t = wdelta(wsub(c, wmul4(d)), wc);
@@ -247,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
     const Fr idz = fe_mul<FrP>(z, prod4(f[0], f[1], f[2], f[3]));                          // ABI (1, <2)
 #pragma unroll
     for (int j = 0; j < 4; ++j) f[j] = perm_factor(w[j], ld_canon(p.s[j], i), kc.beta, gamma);
-    const Fr cpz = fe_mul<FrP>(ld_canon(p.z, inext), prod4(f[0], f[1], f[2], f[3]));      // ABI (1, <2)
+    const Fr cpz = fe_mul<FrP>(ld_canon(PLANAR && in_halo ? L.halo_z : p.z, inext), prod4(f[0], f[1], f[2], f[3]));   // ABI (1, <2)
     // idz - cpz + 3r: (4, <5); times alpha -> ABI (1, <2)
     g = fe_add<FrP>(g, fe_mul<FrP>(fe_sub<FrP, 3, 1>(idz, cpz), fr_limbs(kc.alpha)));
     // (z - 1) l1 alpha^2:  z - 1 + 2r is (4, <3); product with ABI l1 is 2^251, alpha2 restores 2^256
@@ -258,6 +279,43 @@ __global__ void __launch_bounds__(256, 2) quotient_kernel(const QuotPtrs p, cons
   }
 }
 
+// sigma_j(w^i) = k_j' w^i' for a slice of the copy permutation given as wire positions q = j' n + i' (preprocessing; r01 - r04
+// gathered these on the host: 4 n field products or a 4 n x 32-byte round trip through host memory)
+struct SigmaConsts {
+  u32 ks[4][9];   // 1, k_1, k_2, k_3 in device form
+};
+__global__ void __launch_bounds__(256) sigma_eval_kernel(const long long* idx, size_t count, const u32x4* tlo, const u32x4* thi, u32 h,
+                                                         u32 log_n, const SigmaConsts kc, u32x4* out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t mask_n = ((size_t)1 << log_n) - 1, mask_lo = ((size_t)1 << h) - 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const size_t q = (size_t)idx[i], jj = (q >> log_n) & 3, ii = q & mask_n;
+    Fr v = fe_mul<FrP>(ld_canon(tlo, ii & mask_lo), to_dev(ld_canon(thi, ii >> h)));   // ABI x device -> ABI, (1, <2)
+    const Fr k = jj == 0 ? fr_limbs(kc.ks[0]) : (jj == 1 ? fr_limbs(kc.ks[1]) : (jj == 2 ? fr_limbs(kc.ks[2]) : fr_limbs(kc.ks[3])));
+    st_canon(out, i, fe_mul<FrP>(v, k));
+  }
+}
+
+// The distributed prover's way onto the 4n coset (prover_dist.hip.h): out[(4 j + s) m + i] = src_j[i] g_s^(lo + i) for the P
+// polynomials of a batch and the four sub-cosets -- the inputs of 4 P size-n transforms over the ranks, one launch.
+struct CosetExpandArgs {
+  const u32x4* src[8];
+  u32 count;
+};
+__global__ void __launch_bounds__(256) coset_expand_kernel(const CosetExpandArgs a, const u32x4* gs_pow /* [4][m] */, size_t m,
+                                                           u32x4* out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    Fr g[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) g[s_] = to_dev(ld_canon(gs_pow, (size_t)s_ * m + i));
+    for (u32 j = 0; j < a.count; ++j) {
+      const Fr v = ld_canon(a.src[j], i);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) st_canon(out, ((size_t)4 * j + s_) * m + i, fe_mul<FrP>(v, g[s_]));   // ABI x device -> ABI
+    }
+  }
+}
 static HFr load_fr(const uint64_t v[4]) {
   HFr r;
   memcpy(r.l, v, 32);
@@ -280,6 +338,65 @@ static void fill_round_consts(RoundConsts& kc, const HFr& alpha, const HFr& beta
 static unsigned grid_for(const pm_ctx* ctx, size_t n) {
   return (unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cus * 16);
 }
+
+int coset_expand(pm_ctx* ctx, const void* const* d_src, uint32_t count, const void* d_gs_pow, size_t m, void* d_out) {
+  if (!ctx || !d_src || count == 0 || count > 8 || !d_gs_pow || !d_out) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CosetExpandArgs a;
+  memset(&a, 0, sizeof a);
+  a.count = count;
+  for (uint32_t j = 0; j < count; ++j) a.src[j] = (const u32x4*)d_src[j];
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  ProfScope prof(ctx, ctx->stream, "plonk_coset_expand");
+  hipLaunchKernelGGL(coset_expand_kernel, dim3(grid_for(ctx, m)), dim3(256), 0, ctx->stream, a, (const u32x4*)d_gs_pow, m,
+                     (u32x4*)d_out);
+  PM_HIP(ctx, hipGetLastError());
+  return PM_OK;
+}
+
+// out[p] = k_j' w^i' for p < count, q = idx[p] = j' n + i' (host indices, already range-checked by the caller): two-level
+// tables of w (2 sqrt(n) entries) built on the device, one gather kernel.  Synchronises the context before it returns.
+int sigma_evals_from_index(pm_ctx* ctx, const int64_t* idx, size_t count, uint32_t log_n, const uint64_t omega[4],
+                           const uint64_t k[3][4], void* d_out) {
+  if (!ctx || !idx || !omega || !k || !d_out) return PM_ERR_BAD_ARG;
+  if (count == 0) return PM_OK;
+  const host::Field<4>& F = host::FR();
+  const uint32_t h = (log_n + 1) / 2;
+  const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (log_n - h);
+  void *d_idx = nullptr, *d_lo = nullptr, *d_hi = nullptr;
+  struct Free3 {
+    pm_ctx* c;
+    void **a, **b, **d;
+    ~Free3() {
+      for (void** p : {a, b, d})
+        if (*p) (void)pm_dev_free(c, *p);
+    }
+  } free3{ctx, &d_idx, &d_lo, &d_hi};
+  int rc = pm_dev_alloc(ctx, count * 8, &d_idx);
+  if (!rc) rc = pm_dev_alloc(ctx, nlo * 32, &d_lo);
+  if (!rc) rc = pm_dev_alloc(ctx, nhi * 32, &d_hi);
+  if (rc) return rc;
+  const HFr w = load_fr(omega), one = host::one(F);
+  host::u64 e[1] = {(host::u64)nlo};
+  const HFr step = host::pow<4>(w, e, 1, F);
+  rc = pm_fr_powers_dev(ctx, w.l, one.l, nlo, d_lo, nullptr);
+  if (!rc) rc = pm_fr_powers_dev(ctx, step.l, one.l, nhi, d_hi, nullptr);
+  if (!rc) rc = pm_dev_upload(ctx, d_idx, idx, count * 8);
+  if (rc) return rc;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    SigmaConsts kc;
+    to_limbs29_shift(kc.ks[0], one, 1);
+    for (int j = 0; j < 3; ++j) to_limbs29_shift(kc.ks[j + 1], load_fr(k[j]), 1);
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    ProfScope prof(ctx, ctx->stream, "plonk_sigma_evals");
+    hipLaunchKernelGGL(sigma_eval_kernel, dim3(grid_for(ctx, count)), dim3(256), 0, ctx->stream, (const long long*)d_idx, count,
+                       (const u32x4*)d_lo, (const u32x4*)d_hi, h, log_n, kc, (u32x4*)d_out);
+    PM_HIP(ctx, hipGetLastError());
+  }
+  return pm_sync(ctx);   // the temporaries go away when this returns
+}
+
 
 }  // namespace pm
 
@@ -363,6 +480,10 @@ extern "C" int pm_plonk_quotient_dev(pm_ctx* ctx, const pm_plonk_quotient_args* 
 }
 int pm::plonk_quotient_rows(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, bool halo, void* d_out,
                             void* hip_stream) {
+  return plonk_quotient_layout(ctx, args, n, halo, nullptr, d_out, hip_stream);
+}
+int pm::plonk_quotient_layout(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t n, bool halo, const QuotPlanar* planar,
+                              void* d_out, void* hip_stream) {
   if (!ctx) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!args) return set_err(ctx, PM_ERR_BAD_ARG, "null args");
@@ -423,12 +544,26 @@ int pm::plonk_quotient_rows(pm_ctx* ctx, const pm_plonk_quotient_args* args, siz
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   ProfScope prof(ctx, st, "plonk_quotient");
-  if (widgets)
-    hipLaunchKernelGGL(quotient_kernel<true>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n,
-                       4 * n + (halo ? 4 : 0));
-  else
-    hipLaunchKernelGGL(quotient_kernel<false>, dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n,
-                       4 * n + (halo ? 4 : 0));
+  QuotLayout L;
+  memset(&L, 0, sizeof L);
+  const size_t wrap = 4 * n + (halo ? 4 : 0);
+  if (planar) {
+    while (((size_t)1 << L.log_m) < n) ++L.log_m;
+    L.n2 = planar->n2;
+    L.rot = planar->rot;
+    for (int j = 0; j < 4; ++j) L.halo_w[j] = (const u32x4*)planar->halo_w[j];
+    L.halo_z = (const u32x4*)planar->halo_z;
+    if (!L.halo_z || !L.halo_w[0] || !L.halo_w[1] || !L.halo_w[3] || L.n2 == 0 || (L.n2 & (L.n2 - 1)) || L.n2 > n)
+      return set_err(ctx, PM_ERR_BAD_ARG, "planar quotient layout: halo rows missing or row length not a power of two <= rows");
+    if (widgets)
+      hipLaunchKernelGGL((quotient_kernel<true, true>), dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n, wrap, L);
+    else
+      hipLaunchKernelGGL((quotient_kernel<false, true>), dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n, wrap, L);
+  } else if (widgets) {
+    hipLaunchKernelGGL((quotient_kernel<true, false>), dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n, wrap, L);
+  } else {
+    hipLaunchKernelGGL((quotient_kernel<false, false>), dim3(grid_for(ctx, 4 * n)), dim3(256), 0, st, p, kc, wc, 4 * n, wrap, L);
+  }
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
 }

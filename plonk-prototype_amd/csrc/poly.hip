@@ -65,6 +65,17 @@ PM_DEV Fr block_sum_256(Fr v, u32* sh /* 256 * 9 words */) {
   }
   return v;
 }
+// the two power tables of one evaluation in ONE launch (two launches of ~12 us each were a third of a small circuit's
+// opening round): xpow[t] = x^t for t < 256 and xblk[b] = x^(b SEG)
+__global__ void __launch_bounds__(256) eval_tables_kernel(u32x4* xpow, u32x4* xblk, const NttConsts c, u32 nblocks, u32 seg) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 256u) {
+    st_tw(xpow, i, fr_canon(fr_pow(fr_limbs(c.w8[0]), i, fr_limbs(c.scale))));
+  } else if (i - 256u < nblocks) {
+    const u32 b = i - 256u;
+    st_tw(xblk, b, fr_canon(fr_pow(fr_limbs(c.w8[0]), (unsigned long long)b * seg, fr_limbs(c.scale))));
+  }
+}
 // partial[b] = x^(b SEG) * sum_{i in segment b} c_i x^(i - b SEG),  SEG = 256 L, strided Horner
 struct EvalPolys {
   const u32x4* p[PM_LINCOMB_MAX];   // blockIdx.y selects the polynomial
@@ -821,6 +832,55 @@ extern "C" int pm_fr_vec_op_dev(pm_ctx* ctx, int op, const void* d_a, const void
   return PM_OK;
 }
 
+// One evaluation batch, enqueued on `st` without a host synchronisation: the tables, partial sums and results of batch
+// number `slot` live in their own region of the context's polynomial workspace (`slot_bytes` apart), the results are copied
+// to `out` by the stream.  The caller holds ctx->mu and the polynomial resource group and synchronises the stream.
+static size_t eval_slot_bytes(uint32_t k, size_t n) {
+  const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
+  const size_t seg = (size_t)256 * L;
+  const size_t nblocks = (n + seg - 1) / seg;
+  return ((256 + (1 + (size_t)k) * nblocks) * 48 + 32 * (size_t)k + 64 + 255) / 256 * 256;
+}
+static int eval_enqueue(pm_ctx* ctx, hipStream_t st, uint32_t k, const void* const* d_polys, size_t n, const uint64_t point[4],
+                        uint64_t* out, char* ws) {
+  EvalPolys polys;
+  memset(&polys, 0, sizeof polys);
+  for (uint32_t j = 0; j < k; ++j) {
+    if (!d_polys[j]) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
+    polys.p[j] = (const u32x4*)d_polys[j];
+  }
+  const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
+  const size_t seg = (size_t)256 * L;
+  const u32 nblocks = (u32)((n + seg - 1) / seg);
+  HFr x;
+  memcpy(x.l, point, 32);
+  EvalConsts kc;
+  to_limbs29(kc.x, x);
+  to_limbs29(kc.xrow, hfr_pow_u64(x, 256));
+  to_limbs29(kc.xseg, hfr_pow_u64(x, seg));
+  to_limbs29(kc.one, host::one(host::FR()));
+  u32x4* xpow = (u32x4*)ws;
+  u32x4* xblk = xpow + 3 * 256;
+  u32x4* partial = xblk + 3 * (size_t)nblocks;
+  u32x4* d_out = partial + 3 * (size_t)nblocks * k;
+  {
+    NttConsts c;
+    memset(&c, 0, sizeof c);
+    memcpy(c.w8[0], kc.x, sizeof kc.x);
+    memcpy(c.scale, kc.one, sizeof kc.one);
+    hipLaunchKernelGGL(eval_tables_kernel, dim3((256 + nblocks + 255) / 256), dim3(256), 0, st, xpow, xblk, c, nblocks, (u32)seg);
+  }
+  {
+    ProfScope prof(ctx, st, "fr_poly_evaluate");
+    hipLaunchKernelGGL(poly_eval_kernel, dim3(nblocks, k), dim3(256), 0, st, polys, n, L, kc, (const u32x4*)xpow,
+                       (const u32x4*)xblk, partial);
+    hipLaunchKernelGGL(poly_eval_final_kernel, dim3(k), dim3(256), 0, st, (const u32x4*)partial, nblocks, d_out);
+  }
+  PM_HIP(ctx, hipGetLastError());
+  PM_HIP(ctx, hipMemcpyAsync(out, d_out, 32 * (size_t)k, hipMemcpyDeviceToHost, st));
+  return PM_OK;
+}
+
 extern "C" int pm_fr_poly_evaluate_many_dev(pm_ctx* ctx, uint32_t k, const void* const* d_polys, size_t n,
                                             const uint64_t point[4], uint64_t* out, void* hip_stream) {
   if (!ctx || !point || !out) return PM_ERR_BAD_ARG;
@@ -832,50 +892,42 @@ extern "C" int pm_fr_poly_evaluate_many_dev(pm_ctx* ctx, uint32_t k, const void*
     return PM_OK;
   }
   if (!d_polys) return set_err(ctx, PM_ERR_BAD_ARG, "null pointer");
-  EvalPolys polys;
-  memset(&polys, 0, sizeof polys);
-  for (uint32_t j = 0; j < k; ++j) {
-    if (!d_polys[j]) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
-    polys.p[j] = (const u32x4*)d_polys[j];
-  }
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   OrderScope order_scope(ctx, ctx->ord_poly, st);
   int rc = order_scope.rc;
   if (rc) return rc;
-  const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
-  const size_t seg = (size_t)256 * L;
-  const u32 nblocks = (u32)((n + seg - 1) / seg);
-  HFr x;
-  memcpy(x.l, point, 32);
-  EvalConsts kc;
-  to_limbs29(kc.x, x);
-  to_limbs29(kc.xrow, hfr_pow_u64(x, 256));
-  to_limbs29(kc.xseg, hfr_pow_u64(x, seg));
-  to_limbs29(kc.one, host::one(host::FR()));
-  rc = ensure_buffer(ctx, ctx->poly_ws, (size_t)(256 + (1 + (size_t)k) * nblocks) * 48 + 32 * (size_t)k + 64);
+  rc = ensure_buffer(ctx, ctx->poly_ws, eval_slot_bytes(k, n));
   if (rc) return rc;
-  u32x4* xpow = (u32x4*)ctx->poly_ws.ptr;
-  u32x4* xblk = xpow + 3 * 256;
-  u32x4* partial = xblk + 3 * (size_t)nblocks;
-  u32x4* d_out = partial + 3 * (size_t)nblocks * k;
-  {
-    NttConsts c;
-    memset(&c, 0, sizeof c);
-    memcpy(c.w8[0], kc.x, sizeof kc.x);
-    memcpy(c.scale, kc.one, sizeof kc.one);
-    hipLaunchKernelGGL(pow_table_kernel, dim3(1), dim3(256), 0, st, xpow, c, 256u, 1u);
-    hipLaunchKernelGGL(pow_table_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, st, xblk, c, nblocks, (u32)seg);
-  }
-  {
-    ProfScope prof(ctx, st, "fr_poly_evaluate");
-    hipLaunchKernelGGL(poly_eval_kernel, dim3(nblocks, k), dim3(256), 0, st, polys, n, L, kc, (const u32x4*)xpow,
-                       (const u32x4*)xblk, partial);
-    hipLaunchKernelGGL(poly_eval_final_kernel, dim3(k), dim3(256), 0, st, (const u32x4*)partial, nblocks, d_out);
-  }
-  PM_HIP(ctx, hipGetLastError());
-  PM_HIP(ctx, hipMemcpyAsync(out, d_out, 32 * (size_t)k, hipMemcpyDeviceToHost, st));
+  rc = eval_enqueue(ctx, st, k, d_polys, n, point, out, (char*)ctx->poly_ws.ptr);
+  if (rc) return rc;
   PM_HIP(ctx, hipStreamSynchronize(st));
+  return PM_OK;
+}
+// Two batches at two points (the prover's openings at z and z w) with ONE host synchronisation, on the context's stream.
+int pm::poly_evaluate_two(pm_ctx* ctx, uint32_t k1, const void* const* polys1, const uint64_t point1[4], uint64_t* out1, uint32_t k2,
+                          const void* const* polys2, const uint64_t point2[4], uint64_t* out2, size_t n) {
+  if (!ctx || !polys1 || !polys2 || !point1 || !point2 || !out1 || !out2 || n == 0) return PM_ERR_BAD_ARG;
+  if (k1 == 0 || k2 == 0 || k1 > PM_LINCOMB_MAX || k2 > PM_LINCOMB_MAX) return PM_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  PM_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  OrderScope order_scope(ctx, ctx->ord_poly, st);
+  int rc = order_scope.rc;
+  if (rc) return rc;
+  const size_t s1 = eval_slot_bytes(k1, n), s2 = eval_slot_bytes(k2, n);
+  rc = ensure_buffer(ctx, ctx->poly_ws, s1 + s2);
+  if (rc) return rc;
+  // results through pinned memory: a copy to the caller's pageable arrays would block the host until the first batch is done
+  if (!ctx->poly_host_pinned) PM_HIP(ctx, hipHostMalloc(&ctx->poly_host_pinned, 2 * PM_LINCOMB_MAX * 32, hipHostMallocDefault));
+  uint64_t* h1 = (uint64_t*)ctx->poly_host_pinned;
+  uint64_t* h2 = h1 + 4 * PM_LINCOMB_MAX;
+  rc = eval_enqueue(ctx, st, k1, polys1, n, point1, h1, (char*)ctx->poly_ws.ptr);
+  if (!rc) rc = eval_enqueue(ctx, st, k2, polys2, n, point2, h2, (char*)ctx->poly_ws.ptr + s1);
+  if (rc) return rc;
+  PM_HIP(ctx, hipStreamSynchronize(st));
+  memcpy(out1, h1, 32 * (size_t)k1);
+  memcpy(out2, h2, 32 * (size_t)k2);
   return PM_OK;
 }
 

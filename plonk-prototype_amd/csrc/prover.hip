@@ -378,7 +378,6 @@ extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[
   for (const Alloc& a : allocs)
     if ((rc = pm_dev_alloc(ctx, a.elems * 32, a.p)) != PM_OK) break;
   void* tmp = nullptr;
-  std::vector<u64> table, gathered;
   if (!rc) rc = pm_fr_powers_dev(ctx, pk->omega.l, one.l, n, pk->roots, nullptr);
   if (!rc) rc = pm_fr_powers_dev(ctx, omega4.l, g.l, 4 * n, pk->x4, nullptr);
   // selectors: evaluations -> coefficients -> 4n coset (only the coset forms the quotient kernel reads)
@@ -392,28 +391,21 @@ extern "C" int pm_plonk_preprocess(pm_ctx* ctx, const uint64_t* const selectors[
   for (int s = 0; s < NSEL && !rc; ++s)
     if (pk->sel_coset[s])
       rc = pm_fr_ntt_dev(ctx, at(pk->sel_coeffs, s * n), n, n, pk->sel_coset[s], 4 * n, lg + 2, 1, PM_NTT_COSET, nullptr);
-  // sigma_j(w^i) = k_j' w^i': gather from the table of the 4n points of the cosets k_j H
-  if (!rc) {
-    const HFr ks[4] = {one, pk->k[0], pk->k[1], pk->k[2]};
-    for (int j = 0; j < 4 && !rc; ++j) rc = pm_fr_powers_dev(ctx, pk->omega.l, ks[j].l, n, at(tmp, j * n), nullptr);
-  }
-  if (!rc) {
-    table.resize(16 * n);
-    gathered.resize(16 * n);
-    rc = pm_dev_download(ctx, table.data(), tmp, 4 * n * 32);
-  }
+  // sigma_j(w^i) = k_j' w^i': the indices are checked here (a permutation of the 4n wire positions), the values gathered on
+  // the device (r01 - r04: a 4n x 32-byte table went to the host and back)
   if (!rc) {
     std::vector<uint8_t> seen(4 * n, 0);
     for (size_t p = 0; p < 4 * n && !rc; ++p) {
       const int64_t q = sigma_index[p];
       if (q < 0 || (size_t)q >= 4 * n || seen[q]) rc = PM_ERR_BAD_ARG;   // not a permutation
-      else {
-        seen[q] = 1;
-        memcpy(&gathered[4 * p], &table[4 * (size_t)q], 32);
-      }
+      else seen[q] = 1;
     }
   }
-  if (!rc) rc = pm_dev_upload(ctx, pk->sigma_evals, gathered.data(), 4 * n * 32);
+  if (!rc) {
+    u64 kk[3][4];
+    for (int j = 0; j < 3; ++j) put(kk[j], pk->k[j]);
+    rc = pm::sigma_evals_from_index(ctx, sigma_index, 4 * n, lg, pk->omega.l, kk, pk->sigma_evals);
+  }
   if (!rc) rc = pm_fr_ntt_dev(ctx, pk->sigma_evals, n, n, pk->sigma_coeffs, n, lg, 4, PM_NTT_INVERSE, nullptr);
   if (!rc) rc = pm_fr_ntt_dev(ctx, pk->sigma_coeffs, n, n, pk->sigma_coset, 4 * n, lg + 2, 4, PM_NTT_COSET, nullptr);
   // L_1 = (1/n) sum X^i on the coset
@@ -459,6 +451,10 @@ struct Shard {
 };
 // One exchange of k partial points (k = 0: the abort marker).
 static int shard_exchange(pm_ctx* ctx, const Shard& sh, u64* xyz, uint32_t k) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ++ctx->stat_allgather_calls;
+  }
   const int rc = sh.fn ? (sh.fn(sh.user, xyz, k) != 0 ? PM_ERR_EXCHANGE : PM_OK) : pm_g1_allgather_fold(ctx, xyz, k);
   ++sh.done;
   if (k == 0 || rc != PM_OK) sh.aborted = true;
@@ -856,9 +852,8 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     at_z[9] = at(pk->sel_coeffs, Q_L * n);
     at_z[10] = at(pk->sel_coeffs, Q_R * n);
     for (int i = 0; i < 4; ++i) at_z[11 + i] = at(pk->t, i * n);
-    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 15, at_z, n, zc.l, &out_z[0][0], nullptr));
     const void* at_zw[4] = {at(pk->coeffs, 0), at(pk->coeffs, n), at(pk->coeffs, 3 * n), z_coeffs};
-    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 4, at_zw, n, zw.l, &out_zw[0][0], nullptr));
+    PK_TRY(pm::poly_evaluate_two(ctx, 15, at_z, zc.l, &out_z[0][0], 4, at_zw, zw.l, &out_zw[0][0], n));   // one synchronisation
     for (int j = 0; j < 4; ++j) ev[E_A + j] = get(out_z[j]);
     for (int j = 0; j < 3; ++j) ev[E_S1 + j] = get(out_z[4 + j]);
     ev[E_QARITH] = get(out_z[7]);

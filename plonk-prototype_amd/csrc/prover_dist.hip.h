@@ -9,32 +9,40 @@
 //     points  k in [r m, (r + 1) m) of each of the four sub-cosets  g w4^s H  (s = 0 .. 3) of the 4n coset
 // and nothing else: workspace / W, no replicated transform.  What the single-GPU prover does with a size-4n coset
 // transform of a degree < n polynomial is four size-n transforms here (the 4n coset g <w4> is the union of the sub-cosets
-// g_s H, g_s = g w4^s: f(g_s w^k) = NTT_n(f_i g_s^i)[k]), each one pm_fr_ntt_fourstep_dev over the ranks (the all-to-all of
-// section 7.5); the quotient kernel runs on the rank's rows in the same interleaved order (index 4 k + s) as on one GPU,
-// with a four-point halo from the next rank for z(w X) and the next-row wires; the quotient's coefficients come back
-// through four inverse transforms and a pointwise 4-point inverse DFT; prefix product, openings and Ruffini division
+// g_s H, g_s = g w4^s: f(g_s w^k) = NTT_n(f_i g_s^i)[k]) over the ranks (the all-to-all of section 7.5).
+// r05: the exchanges are cut by construction.  All polynomials of a round go through ONE batched transform
+// (pm_fr_ntt_fourstep_batch_dev: the all-to-all carries the whole batch), everything on the coset stays in the BLOCK-
+// TRANSPOSED order the forward transform leaves after its second all-to-all (PM_NTT_TRANSPOSED: four planes [s][m] per
+// polynomial, position k1_local N2 + k2 <-> k = k2 N1 + k1) -- the quotient is pointwise and does not care -- and the one thing
+// that is not pointwise, z(w X) and the next-row wires = index k + 1 = one row down, comes from a HALO ROW that the same
+// second all-to-all delivers as one more column per peer.  The quotient's coefficients come back through ONE batched
+// inverse transform that takes the transposed order (two all-to-alls) and a pointwise 4-point inverse DFT.  Per proof:
+// 3 + 2 (wires and public inputs: to coefficients, onto the coset) + 3 + 2 (z) + 2 (quotient) = 12 all-to-all calls, where
+// r04 made 3 per transform x 34 transforms = 102 (pm_comm_stats counts them).  Prefix product, openings and Ruffini division
 // are local passes plus one fixed-size all-gather of per-rank scalars each.  Every exchange besides the all-to-all is
-// the SAME 2312-byte message all-gather as the sharded prover's (count word 0 = abort marker): 10 per proof, the first an
+// the SAME 2312-byte message all-gather as the sharded prover's (count word 0 = abort marker): 9 per proof, the first an
 // agreement on the arguments: a rank whose arguments are bad meets its peers there with the marker.  (A rank that fails
 // LATER, between two all-to-alls -- a HIP error, an allocation -- returns its error; its peers see the marker at their next
 // all-gather but cannot see it inside an all-to-all: treat such an error as fatal for the group.)
 // Results are bit-identical to pm_plonk_prove (tests/test_gpu_dist_prover_n5.py).
 
+static constexpr uint32_t DIST_MAX_VECS = 20;   // vectors of one batched transform (5 polynomials x 4 sub-cosets): sizes the stage buffer
 struct pm_dist_key {
-  size_t n = 0, m = 0, lo = 0;
+  size_t n = 0, m = 0, lo = 0, n2 = 0;   // n2: row length of the block-transposed order, 2^(log_n - log_n / 2)
   uint32_t log_n = 0, world = 1, rank = 0;
   HFr omega, k[3], zh_inv[4], gs[4];
-  // device arrays (element counts in units of m = n / world)
-  void *roots = nullptr /* m */, *x4 = nullptr /* 4m */, *gs_pow = nullptr /* 4m: g_s^i */, *gs_inv_pow = nullptr /* 4m */,
+  // device arrays (element counts in units of m = n / world); "coset" arrays are four planes [s][m], block-transposed order
+  void *roots = nullptr /* m */, *gs_pow = nullptr /* 4m: g_s^i */, *gs_inv_pow = nullptr /* 4m */,
        *sel_coeffs = nullptr /* 11m */, *sigma_evals = nullptr /* 4m */, *sigma_coeffs = nullptr /* 4m */,
-       *sigma_coset = nullptr /* 16m */, *l1_coset = nullptr /* 4m */;
-  void* sel_coset[NSEL] = {};
+       *sigma_coset = nullptr /* 16m */, *lx_coset = nullptr /* 8m: L_1, then the coset points x */, *sel_coset_all = nullptr;
+  void* sel_coset[NSEL] = {};   // into sel_coset_all
   bool sel_zero[NSEL] = {};
   bool arith_is_one = false;
-  // per-proof workspace: coeffs [a b c d z pi] 6m | num m | den m | coset 6 (4m + 4) | t 4m | tq 4m | r m | agg 2m | wit 2m |
-  // pi m | stage 2m | tmp 4m | one scalar
-  void *coeffs = nullptr, *num = nullptr, *den = nullptr, *coset = nullptr, *t = nullptr, *tq = nullptr, *r = nullptr,
-       *agg = nullptr, *wit = nullptr, *pi_evals = nullptr, *stage = nullptr, *tmp = nullptr, *scalar = nullptr;
+  // per-proof workspace: coeffs [a b c d pi z] 6m | num m | den m | coset_a 20m + 20 n2 halo rows | coset_z 4m + 4 n2 | tq 4m |
+  // t 4m | r m | agg 2m | wit 2m | stage 2 x 20 (m + n2) | tmp m | one scalar
+  void *coeffs = nullptr, *num = nullptr, *den = nullptr, *coset_a = nullptr, *halo_a = nullptr, *coset_z = nullptr,
+       *halo_z = nullptr, *t = nullptr, *tq = nullptr, *r = nullptr, *agg = nullptr, *wit = nullptr, *stage = nullptr,
+       *tmp = nullptr, *scalar = nullptr;
   size_t device_bytes = 0;   // what this rank holds for the key and its workspace
   bool committed = false;
   u64 vk[NSEL + 4][12] = {};
@@ -63,6 +71,10 @@ int dist_exchange(pm_ctx* ctx, Dist& D, const std::vector<u64>& msg, std::vector
       rc = pm::comm_allgather_msg(ctx, msg.data(), gathered.data());
   }
   ++D.done;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ++ctx->stat_allgather_calls;
+  }
   if (rc == PM_OK && msg[0] == 0) rc = PM_ERR_EXCHANGE;
   for (uint32_t r = 0; r < D.d.world && rc == PM_OK; ++r)
     if (gathered[r * pm::COMM_MSG_WORDS] != msg[0]) rc = PM_ERR_EXCHANGE;   // a peer gave up, or the ranks are out of step
@@ -97,31 +109,19 @@ int dist_scalars(pm_ctx* ctx, Dist& D, const HFr* vals, uint32_t k, std::vector<
 }
 HFr fpow64(const HFr& a, u64 e) { return fpow(a, e); }
 
-// one size-n transform over the ranks, in place on this rank's m-element block (natural order in and out)
-int dist_ntt(pm_ctx* ctx, const Dist& D, const pm_dist_key* pk, void* d_block, uint32_t flags) {
-  return pm_fr_ntt_fourstep_dev(ctx, d_block, pk->stage, pk->log_n, D.d.world, D.d.rank, flags, D.d.alltoall, D.d.user);
+// `batch` size-n transforms over the ranks in ONE sequence of exchanges, in place on contiguous m-element blocks
+int dist_ntt(pm_ctx* ctx, const Dist& D, const pm_dist_key* pk, void* d_blocks, uint32_t batch, void* d_halo, uint32_t flags) {
+  if (batch > DIST_MAX_VECS) return PM_ERR_BAD_ARG;
+  return pm_fr_ntt_fourstep_batch_dev(ctx, d_blocks, batch, d_halo, pk->stage, pk->log_n, D.d.world, D.d.rank, flags, D.d.alltoall,
+                                      D.d.user);
 }
-// rows [4 k + s] <- src[k]: the interleaved order of the 4n coset
-int interleave(pm_ctx* ctx, void* d_il, int s, const void* d_src, size_t m) {
-  PM_HIP(ctx, hipSetDevice(ctx->device));
-  PM_HIP(ctx, hipMemcpy2DAsync((char*)d_il + 32 * s, 128, d_src, 32, 32, m, hipMemcpyDeviceToDevice, ctx->stream));
-  return PM_OK;
-}
-int deinterleave(pm_ctx* ctx, void* d_dst, const void* d_il, int s, size_t m) {
-  PM_HIP(ctx, hipSetDevice(ctx->device));
-  PM_HIP(ctx, hipMemcpy2DAsync(d_dst, 32, (const char*)d_il + 32 * s, 128, 32, m, hipMemcpyDeviceToDevice, ctx->stream));
-  return PM_OK;
-}
-// coefficients [lo, lo + m) of a polynomial of degree < n  ->  its values on the rank's points of the four sub-cosets,
-// interleaved ([4 k + s], k local): four size-n transforms over the ranks
-int dist_to_coset(pm_ctx* ctx, const Dist& D, const pm_dist_key* pk, const void* d_coeffs, void* d_il) {
-  const size_t m = pk->m;
-  for (int s = 0; s < 4; ++s) {
-    PK_TRY(pm_fr_vec_op_dev(ctx, 2, d_coeffs, at(pk->gs_pow, s * m), m, pk->tmp, m, nullptr));
-    PK_TRY(dist_ntt(ctx, D, pk, pk->tmp, 0));
-    PK_TRY(interleave(ctx, d_il, s, pk->tmp, m));
-  }
-  return PM_OK;
+// coefficients [lo, lo + m) of `count` <= 5 polynomials of degree < n  ->  their values on the rank's points of the four
+// sub-cosets: planes [4 j + s][m] of d_planes in block-transposed order (+ the halo rows [4 j + s][n2], when asked for).
+// One expansion kernel (f_i g_s^i), one batched transform: two all-to-alls whatever the count.
+int dist_to_coset(pm_ctx* ctx, const Dist& D, const pm_dist_key* pk, const void* const* d_coeffs, uint32_t count, void* d_planes,
+                  void* d_halo) {
+  PK_TRY(pm::coset_expand(ctx, d_coeffs, count, pk->gs_pow, pk->m, d_planes));
+  return dist_ntt(ctx, D, pk, d_planes, 4 * count, d_halo, PM_NTT_TRANSPOSED);
 }
 int upload_scalar(pm_ctx* ctx, const pm_dist_key* pk, const HFr& v) {
   PK_TRY(pm_sync(ctx));   // the previous user of the one-scalar buffer has finished
@@ -166,11 +166,9 @@ int dist_check(const pm_dist* d, size_t n) {
 extern "C" void pm_plonk_dist_key_free(pm_ctx* ctx, pm_dist_key* pk) {
   if (!pk) return;
   if (ctx) (void)pm_sync(ctx);
-  for (void* p : {pk->roots, pk->x4, pk->gs_pow, pk->gs_inv_pow, pk->sel_coeffs, pk->sigma_evals, pk->sigma_coeffs, pk->sigma_coset,
-                  pk->l1_coset, pk->coeffs, pk->num, pk->den, pk->coset, pk->t, pk->tq, pk->r, pk->agg, pk->wit, pk->pi_evals,
-                  pk->stage, pk->tmp, pk->scalar})
-    if (p && ctx) (void)pm_dev_free(ctx, p);
-  for (void* p : pk->sel_coset)
+  for (void* p : {pk->roots, pk->gs_pow, pk->gs_inv_pow, pk->sel_coeffs, pk->sigma_evals, pk->sigma_coeffs, pk->sigma_coset,
+                  pk->lx_coset, pk->sel_coset_all, pk->coeffs, pk->num, pk->den, pk->coset_a, pk->halo_a, pk->coset_z, pk->halo_z,
+                  pk->t, pk->tq, pk->r, pk->agg, pk->wit, pk->stage, pk->tmp, pk->scalar})
     if (p && ctx) (void)pm_dev_free(ctx, p);
   delete pk;
 }
@@ -220,12 +218,13 @@ static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uin
     }
     return PM_OK;
   };
-  PK_TRY(alloc_all({{&pk->roots, m},        {&pk->x4, 4 * m},          {&pk->gs_pow, 4 * m},      {&pk->gs_inv_pow, 4 * m},
-                    {&pk->sel_coeffs, (size_t)NSEL * m},               {&pk->sigma_evals, 4 * m}, {&pk->sigma_coeffs, 4 * m},
-                    {&pk->sigma_coset, 16 * m}, {&pk->l1_coset, 4 * m}, {&pk->coeffs, 6 * m},      {&pk->num, m},
-                    {&pk->den, m},          {&pk->coset, 6 * (4 * m + 4)}, {&pk->t, 4 * m},        {&pk->tq, 4 * m},
-                    {&pk->r, m},            {&pk->agg, 2 * m},         {&pk->wit, 2 * m},         {&pk->pi_evals, m},
-                    {&pk->stage, 2 * m},    {&pk->tmp, 4 * m},         {&pk->scalar, 1}}));
+  const size_t n2 = pk->n2;
+  PK_TRY(alloc_all({{&pk->roots, m},          {&pk->gs_pow, 4 * m},      {&pk->gs_inv_pow, 4 * m},  {&pk->sel_coeffs, (size_t)NSEL * m},
+                    {&pk->sigma_evals, 4 * m}, {&pk->sigma_coeffs, 4 * m}, {&pk->sigma_coset, 16 * m}, {&pk->lx_coset, 8 * m},
+                    {&pk->coeffs, 6 * m},      {&pk->num, m},             {&pk->den, m},             {&pk->coset_a, 20 * m},
+                    {&pk->halo_a, 20 * n2},    {&pk->coset_z, 4 * m},     {&pk->halo_z, 4 * n2},     {&pk->t, 4 * m},
+                    {&pk->tq, 4 * m},          {&pk->r, m},               {&pk->agg, 2 * m},         {&pk->wit, 2 * m},
+                    {&pk->stage, 2 * (size_t)DIST_MAX_VECS * (m + n2)},   {&pk->tmp, m},             {&pk->scalar, 1}}));
   // trivial selector polynomials: a GLOBAL property (every rank must take the same branches): local flags, one exchange
   {
     HFr flags[2] = {zero, zero};   // words: [selector non-zero mask, q_arith differs from one, rank, n], [sigma index power sums]
@@ -274,71 +273,74 @@ static int preprocess_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const uin
   {
     // the allocations that depend on the flags, then the SECOND exchange: every rank says it holds everything it needs
     // before anyone enters the first all-to-all (which carries no abort marker and has no timeout)
-    std::vector<Alloc> more;
+    uint32_t count = 0;
+    bool need[NSEL];
     for (int s = 0; s < NSEL; ++s) {
-      const bool need = s <= Q_4 || (s == Q_ARITH ? !pk->arith_is_one : !pk->sel_zero[s]);
-      if (need) more.push_back({&pk->sel_coset[s], 4 * m});
+      need[s] = s <= Q_4 || (s == Q_ARITH ? !pk->arith_is_one : !pk->sel_zero[s]);
+      count += need[s] ? 1u : 0u;
     }
-    PK_TRY(alloc_all(more));
+    PK_TRY(alloc_all({{&pk->sel_coset_all, (size_t)count * 4 * m}}));   // one array: consecutive selectors transform as one batch
+    count = 0;
+    for (int s = 0; s < NSEL; ++s)
+      if (need[s]) pk->sel_coset[s] = at(pk->sel_coset_all, (size_t)count++ * 4 * m);
     HFr ok = zero;
     ok.l[0] = 0x6f6b;
     std::vector<HFr> all;
     PK_TRY(dist_scalars(ctx, D, &ok, 1, all));
   }
-  // this rank's domain points, sub-coset powers g_s^i (i global) and the coset points x = g_s w^k in interleaved order
+  // this rank's domain points and the sub-coset powers g_s^i (i global)
   PK_TRY(pm_fr_powers_dev(ctx, pk->omega.l, fpow64(pk->omega, lo).l, m, pk->roots, nullptr));
   for (int s = 0; s < 4; ++s) {
     const HFr gi = finv(pk->gs[s]);
     PK_TRY(pm_fr_powers_dev(ctx, pk->gs[s].l, fpow64(pk->gs[s], lo).l, m, at(pk->gs_pow, s * m), nullptr));
     PK_TRY(pm_fr_powers_dev(ctx, gi.l, fpow64(gi, lo).l, m, at(pk->gs_inv_pow, s * m), nullptr));
-    PK_TRY(pm_fr_powers_dev(ctx, pk->omega.l, fmul(pk->gs[s], fpow64(pk->omega, lo)).l, m, pk->tmp, nullptr));
-    PK_TRY(interleave(ctx, pk->x4, s, pk->tmp, m));
   }
-  // selectors: rows -> coefficient slices -> the coset forms the quotient kernel reads
+  // selectors: rows -> coefficient slices (ONE batched inverse transform) -> the coset forms the quotient kernel reads, five
+  // polynomials per batched forward transform.  An identically-zero selector with a coset array goes through like the
+  // others: the transform of zeros is zeros (the array was left as allocated).
   for (int s = 0; s < NSEL; ++s) {
     void* dst = at(pk->sel_coeffs, s * m);
-    if (pk->sel_zero[s] || !selector_slices[s]) {
-      PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, m, dst, nullptr));
-      if (pk->sel_zero[s]) {
-        // the zero polynomial on the coset: the quotient kernel reads this array (pm_dev_alloc does not clear)
-        if (pk->sel_coset[s]) PM_HIP(ctx, hipMemsetAsync(pk->sel_coset[s], 0, 4 * m * 32, ctx->stream));
-        continue;
-      }
-    } else {
-      PK_TRY(pm_dev_upload(ctx, dst, selector_slices[s], m * 32));
-    }
-    PK_TRY(dist_ntt(ctx, D, pk, dst, PM_NTT_INVERSE));
-    if (pk->sel_coset[s]) PK_TRY(dist_to_coset(ctx, D, pk, dst, pk->sel_coset[s]));
+    if (pk->sel_zero[s] || !selector_slices[s]) PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, m, dst, nullptr));
+    else PK_TRY(pm_dev_upload(ctx, dst, selector_slices[s], m * 32));
   }
-  // sigma_j(w^i) = k_j' w^i' for this rank's rows: two-level host tables of w (2 sqrt(n) entries) instead of n roots
+  PK_TRY(dist_ntt(ctx, D, pk, pk->sel_coeffs, NSEL, nullptr, PM_NTT_INVERSE));
   {
-    const uint32_t h = (lg + 1) / 2;
-    const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (lg - h);
-    std::vector<HFr> tlo(nlo), thi(nhi);
-    tlo[0] = one;
-    for (size_t i = 1; i < nlo; ++i) tlo[i] = fmul(tlo[i - 1], pk->omega);
-    const HFr step = fmul(tlo[nlo - 1], pk->omega);
-    thi[0] = one;
-    for (size_t i = 1; i < nhi; ++i) thi[i] = fmul(thi[i - 1], step);
-    const HFr ks[4] = {one, pk->k[0], pk->k[1], pk->k[2]};
-    std::vector<u64> vals(16 * m);
-    for (size_t p = 0; p < 4 * m; ++p) {
-      const int64_t q = sigma_index_slices[p];   // checked above
-      const size_t jj = (size_t)q / n, ii = (size_t)q % n;
-      const HFr v = fmul(ks[jj], fmul(thi[ii >> h], tlo[ii & (nlo - 1)]));
-      memcpy(&vals[4 * p], v.l, 32);
+    const void* src[5];
+    void* first = nullptr;
+    uint32_t cnt = 0;
+    for (int s = 0; s <= NSEL; ++s) {
+      if (s < NSEL && pk->sel_coset[s]) {
+        if (!cnt) first = pk->sel_coset[s];
+        src[cnt++] = at(pk->sel_coeffs, s * m);
+      }
+      if (cnt == 5 || (s == NSEL && cnt)) {
+        PK_TRY(dist_to_coset(ctx, D, pk, src, cnt, first, nullptr));
+        cnt = 0;
+      }
     }
-    PK_TRY(pm_dev_upload(ctx, pk->sigma_evals, vals.data(), 4 * m * 32));
   }
-  for (int j = 0; j < 4; ++j) {
-    void* cj = at(pk->sigma_coeffs, j * m);
-    PM_HIP(ctx, hipMemcpyAsync(cj, at(pk->sigma_evals, j * m), m * 32, hipMemcpyDeviceToDevice, ctx->stream));
-    PK_TRY(dist_ntt(ctx, D, pk, cj, PM_NTT_INVERSE));
-    PK_TRY(dist_to_coset(ctx, D, pk, cj, at(pk->sigma_coset, 4 * m * j)));
+  // sigma_j(w^i) = k_j' w^i' for this rank's rows: gathered on the device from two-level tables of w (2 sqrt(n) entries)
+  {
+    u64 kk[3][4];
+    for (int j = 0; j < 3; ++j) put(kk[j], pk->k[j]);
+    PK_TRY(pm::sigma_evals_from_index(ctx, sigma_index_slices, 4 * m, lg, pk->omega.l, kk, pk->sigma_evals));
   }
-  // L_1 = (1/n) sum X^i on the coset
+  PM_HIP(ctx, hipMemcpyAsync(pk->sigma_coeffs, pk->sigma_evals, 4 * m * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  PK_TRY(dist_ntt(ctx, D, pk, pk->sigma_coeffs, 4, nullptr, PM_NTT_INVERSE));
+  {
+    const void* src[4];
+    for (int j = 0; j < 4; ++j) src[j] = at(pk->sigma_coeffs, j * m);
+    PK_TRY(dist_to_coset(ctx, D, pk, src, 4, pk->sigma_coset, nullptr));
+  }
+  // L_1 = (1/n) sum X^i and the polynomial X itself on the coset: the second gives the coset points x = g_s w^k in exactly
+  // the order every other coset array has
   PK_TRY(pm_fr_powers_dev(ctx, one.l, n_inv.l, m, pk->num, nullptr));
-  PK_TRY(dist_to_coset(ctx, D, pk, pk->num, pk->l1_coset));
+  PK_TRY(pm_fr_powers_dev(ctx, zero.l, zero.l, m, pk->den, nullptr));
+  if (lo == 0) PK_TRY(pm_dev_upload(ctx, at(pk->den, 1), one.l, 32));
+  {
+    const void* src[2] = {pk->num, pk->den};
+    PK_TRY(dist_to_coset(ctx, D, pk, src, 2, pk->lx_coset, nullptr));
+  }
   PK_TRY(pm_sync(ctx));
   {
     const HFr gn = fpow(g, n), i4 = fpow(omega4, n);
@@ -367,6 +369,7 @@ extern "C" int pm_plonk_preprocess_dist(pm_ctx* ctx, const pm_dist* dist, const 
   pk->m = n / dist->world;
   pk->lo = pk->m * dist->rank;
   while (((size_t)1 << pk->log_n) < n) ++pk->log_n;
+  pk->n2 = (size_t)1 << (pk->log_n - pk->log_n / 2);
   rc = preprocess_dist_body(ctx, D, pk, selector_slices, sigma_index_slices);
   rc = dist_leave(ctx, D, rc);
   if (rc) {
@@ -446,20 +449,24 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
     }
   }
   const HFr one = fone();
-  const size_t cs = 4 * m + 4;   // a coset array with its halo
-  auto coset = [&](int j) { return at(pk->coset, cs * j); };
+  const size_t n2 = pk->n2;
+  auto coset = [&](int j) { return at(pk->coset_a, 4 * m * j); };   // planes of a, b, c, d (j < 4) and the public inputs (4)
   // ---- round 1 --------------------------------------------------------------------------------
+  // wires and public inputs: ONE batched inverse transform (natural order: the coefficient slices are what the commit key
+  // slice commits to), then ONE batched forward transform onto the four sub-cosets (20 vectors, halo rows with it)
+  void *pi_coeffs = at(pk->coeffs, 4 * m), *z_coeffs = at(pk->coeffs, 5 * m);
   PM_HIP(ctx, hipMemcpyAsync(pk->coeffs, d_witness, 4 * m * 32, hipMemcpyDeviceToDevice, st));
-  for (int j = 0; j < 4; ++j) PK_TRY(dist_ntt(ctx, D, pk, at(pk->coeffs, j * m), PM_NTT_INVERSE));
-  void* pi_coeffs = at(pk->coeffs, 5 * m);
   PM_HIP(ctx, hipMemsetAsync(pi_coeffs, 0, m * 32, st));
   for (size_t i = 0; i < n_pi; ++i)   // a repeated position keeps its last value (stream order)
     if (pi_positions[i] >= lo && pi_positions[i] < lo + m)
       PM_HIP(ctx, hipMemcpyAsync(at(pi_coeffs, pi_positions[i] - lo), pi_values + 4 * i, 32, hipMemcpyHostToDevice, st));
   PM_HIP(ctx, hipStreamSynchronize(st));   // pi_values is the caller's memory
-  PK_TRY(dist_ntt(ctx, D, pk, pi_coeffs, PM_NTT_INVERSE));
-  for (int j = 0; j < 4; ++j) PK_TRY(dist_to_coset(ctx, D, pk, at(pk->coeffs, j * m), coset(j)));
-  PK_TRY(dist_to_coset(ctx, D, pk, pi_coeffs, coset(5)));
+  PK_TRY(dist_ntt(ctx, D, pk, pk->coeffs, 5, nullptr, PM_NTT_INVERSE));
+  {
+    const void* src[5];
+    for (int j = 0; j < 5; ++j) src[j] = at(pk->coeffs, j * m);
+    PK_TRY(dist_to_coset(ctx, D, pk, src, 5, pk->coset_a, pk->halo_a));
+  }
   PK_TRY(commit_batch_dist(ctx, D, pk, ck, pk->coeffs, n, 4, &out->commitments[0]));
   for (int j = 0; j < 4; ++j) ts.append_commitment(tl::WIRES[j], out->commitments[j]);
   // ---- round 2 --------------------------------------------------------------------------------
@@ -493,10 +500,12 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
     PK_TRY(upload_scalar(ctx, pk, carry));
     PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->den, pk->scalar, 1, pk->den, m, nullptr));
   }
-  void* z_coeffs = at(pk->coeffs, 4 * m);
   PM_HIP(ctx, hipMemcpyAsync(z_coeffs, pk->den, m * 32, hipMemcpyDeviceToDevice, st));
-  PK_TRY(dist_ntt(ctx, D, pk, z_coeffs, PM_NTT_INVERSE));
-  PK_TRY(dist_to_coset(ctx, D, pk, z_coeffs, coset(4)));
+  PK_TRY(dist_ntt(ctx, D, pk, z_coeffs, 1, nullptr, PM_NTT_INVERSE));
+  {
+    const void* src[1] = {z_coeffs};
+    PK_TRY(dist_to_coset(ctx, D, pk, src, 1, pk->coset_z, pk->halo_z));
+  }
   PK_TRY(commit_batch_dist(ctx, D, pk, ck, z_coeffs, n, 1, &out->commitments[4]));
   ts.append_commitment(tl::PERM, out->commitments[4]);
   // ---- round 3 --------------------------------------------------------------------------------
@@ -505,25 +514,14 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
   const HFr logic_sep = ts.challenge_scalar(tl::LOGIC_SEP);
   const HFr fixed_sep = ts.challenge_scalar(tl::FIXED_SEP);
   const HFr var_sep = ts.challenge_scalar(tl::VAR_SEP);
-  {
-    // halo: what the quotient kernel reads at index + 4 past this rank's last row = the next rank's first row
-    // (the last rank wraps to the first): z and the wires a, b, d -- 16 scalars per rank, one exchange
-    const int halo_of[4] = {4, 0, 1, 3};
-    HFr first[16];
-    for (int a = 0; a < 4; ++a) PK_TRY(pm_dev_download(ctx, first[4 * a].l, coset(halo_of[a]), 128));
-    std::vector<HFr> all;
-    PK_TRY(dist_scalars(ctx, D, first, 16, all));
-    const HFr* nxt = &all[(size_t)((rk + 1) % W) * 16];
-    for (int a = 0; a < 4; ++a) PK_TRY(pm_dev_upload(ctx, at(coset(halo_of[a]), 4 * m), nxt[4 * a].l, 128));
-  }
   pm_plonk_quotient_args qa;
   memset(&qa, 0, sizeof qa);
   for (int j = 0; j < 4; ++j) {
     qa.wires[j] = coset(j);
     qa.sigmas[j] = at(pk->sigma_coset, 4 * m * j);
   }
-  qa.z = coset(4);
-  qa.pi = coset(5);
+  qa.z = pk->coset_z;
+  qa.pi = coset(4);
   qa.q_m = pk->sel_coset[Q_M];
   qa.q_l = pk->sel_coset[Q_L];
   qa.q_r = pk->sel_coset[Q_R];
@@ -535,8 +533,8 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
   qa.q_logic = pk->sel_coset[Q_LOGIC];
   qa.q_fixed_group_add = pk->sel_coset[Q_FIXED];
   qa.q_variable_group_add = pk->sel_coset[Q_VAR];
-  qa.l1 = pk->l1_coset;
-  qa.x = pk->x4;
+  qa.l1 = pk->lx_coset;
+  qa.x = at(pk->lx_coset, 4 * m);
   put(qa.alpha, alpha);
   put(qa.beta, beta);
   put(qa.gamma, gamma);
@@ -546,16 +544,23 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
   put(qa.var_sep, var_sep);
   for (int j = 0; j < 3; ++j) put(qa.k[j], pk->k[j]);
   for (int j = 0; j < 4; ++j) put(qa.zh_inv[j], pk->zh_inv[j]);
-  PK_TRY(pm::plonk_quotient_rows(ctx, &qa, m, true, pk->tq, nullptr));
   {
-    // t's coefficients from its values on the four sub-cosets: D_s = iNTT_n(t on g_s H), D'_s[i] = D_s[i] g_s^-i
-    //   = sum_m' (c_{i + m' n} g^(n m')) i4^(s m'):  a 4-point DFT over m' for every i, undone pointwise
-    for (int s = 0; s < 4; ++s) {
-      void* ds = at(pk->tmp, s * m);
-      PK_TRY(deinterleave(ctx, ds, pk->tq, s, m));
-      PK_TRY(dist_ntt(ctx, D, pk, ds, PM_NTT_INVERSE));
-      PK_TRY(pm_fr_vec_op_dev(ctx, 2, ds, at(pk->gs_inv_pow, s * m), m, ds, m, nullptr));
-    }
+    // the same kernel on the rank's 4 m points, planar layout: "one row further" is index + n2, and past the rank's last row
+    // the halo rows of a, b, d and z that came with the transforms (the last rank's are rank 0's first rows, shifted by one)
+    pm::QuotPlanar ql;
+    memset(&ql, 0, sizeof ql);
+    ql.n2 = (uint32_t)n2;
+    ql.rot = rk + 1 == W ? 1u : 0u;
+    for (int j = 0; j < 4; ++j) ql.halo_w[j] = at(pk->halo_a, 4 * n2 * j);
+    ql.halo_z = pk->halo_z;
+    PK_TRY(pm::plonk_quotient_layout(ctx, &qa, m, false, &ql, pk->tq, nullptr));
+  }
+  {
+    // t's coefficients from its values on the four sub-cosets: D_s = iNTT_n(t on g_s H) -- ONE batched inverse transform that
+    // takes the block-transposed order --, D'_s[i] = D_s[i] g_s^-i = sum_m' (c_{i + m' n} g^(n m')) i4^(s m'):  a 4-point DFT
+    // over m' for every i, undone pointwise
+    PK_TRY(dist_ntt(ctx, D, pk, pk->tq, 4, nullptr, PM_NTT_INVERSE | PM_NTT_TRANSPOSED));
+    PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->tq, pk->gs_inv_pow, 4 * m, pk->tq, 4 * m, nullptr));
     const HFr i4 = fpow(fmul(pk->gs[1], finv(pk->gs[0])), n), i4_inv = finv(i4);   // w4^n: a primitive fourth root of unity
     const HFr gn_inv = finv(fpow(pk->gs[0], n)), quarter = finv(fr_u64(4));
     HFr gm = one;   // g^(-n m')
@@ -563,7 +568,7 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
       const void* v[4];
       u64 c[4][4];
       for (int s = 0; s < 4; ++s) {
-        v[s] = at(pk->tmp, s * m);
+        v[s] = at(pk->tq, s * m);
         put(c[s], fmul(fmul(quarter, gm), fpow64(i4_inv, (u64)(s * mp))));
       }
       PK_TRY(pm_fr_lincomb_dev(ctx, 4, v, &c[0][0], m, at(pk->t, mp * m), nullptr));
@@ -588,9 +593,8 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
     at_z[9] = at(pk->sel_coeffs, Q_L * m);
     at_z[10] = at(pk->sel_coeffs, Q_R * m);
     for (int i = 0; i < 4; ++i) at_z[11 + i] = at(pk->t, i * m);
-    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 15, at_z, m, zc.l, &out_z[0][0], nullptr));
     const void* at_zw[4] = {at(pk->coeffs, 0), at(pk->coeffs, m), at(pk->coeffs, 3 * m), z_coeffs};
-    PK_TRY(pm_fr_poly_evaluate_many_dev(ctx, 4, at_zw, m, zw.l, &out_zw[0][0], nullptr));
+    PK_TRY(pm::poly_evaluate_two(ctx, 15, at_z, zc.l, &out_z[0][0], 4, at_zw, zw.l, &out_zw[0][0], m));   // one synchronisation
     HFr part[19];
     for (int j = 0; j < 15; ++j) part[j] = fmul(get(out_z[j]), zc_lo);
     for (int j = 0; j < 4; ++j) part[15 + j] = fmul(get(out_zw[j]), zw_lo);
@@ -732,6 +736,6 @@ extern "C" int pm_plonk_prove_dist(pm_ctx* ctx, const pm_dist* dist, pm_dist_key
   if (!ctx || !dist) return PM_ERR_BAD_ARG;
   Dist D;
   D.d = *dist;
-  D.expect = 10;
+  D.expect = 9;
   return dist_leave(ctx, D, prove_dist_body(ctx, D, key, ck_slice, d_witness_slices, pi_positions, pi_values, n_pi, flags, out));
 }

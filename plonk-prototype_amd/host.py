@@ -184,6 +184,22 @@ class Context:
         self._check(self._lib.pm_fr_ntt_fourstep_dev(self._h, C.c_void_p(d_inout), C.c_void_p(d_stage), log_n, world,
                                                      rank, flags, C.cast(cb, C.c_void_p), None))
 
+    def fr_ntt_fourstep_batch_dev(self, d_inout: int, batch: int, d_stage: int, log_n: int, world: int, rank: int,
+                                  flags: int = 0, exchange=None, d_halo: int = 0):
+        """``pm_fr_ntt_fourstep_batch_dev``: `batch` contiguous N / world blocks through ONE sequence of exchanges;
+        ``d_halo`` (forward + NTT_TRANSPOSED only): batch x N2 elements that receive the next rank's first row."""
+        cb = exchange if exchange is not None else C.cast(None, _lib.ALLTOALL_FN)
+        self._check(self._lib.pm_fr_ntt_fourstep_batch_dev(self._h, C.c_void_p(d_inout), batch, C.c_void_p(d_halo or None),
+                                                           C.c_void_p(d_stage), log_n, world, rank, flags,
+                                                           C.cast(cb, C.c_void_p), None))
+
+    def comm_stats(self, reset: bool = False) -> dict:
+        """``pm_comm_stats``: exchange counters of this context since the last reset."""
+        out = np.zeros(4, np.uint64)
+        self._check(self._lib.pm_comm_stats(self._h, _p(out), 1 if reset else 0))
+        return {"alltoall_calls": int(out[0]), "alltoall_bytes": int(out[1]), "allgather_calls": int(out[2]),
+                "transpose_steps": int(out[3])}
+
     # ---- device-pointer forms of the polynomial helpers (ints; used by prover.py) -------
     def fr_powers(self, base, scale, n: int, d_out: int):
         """out[i] = scale * base^i."""

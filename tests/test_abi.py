@@ -107,6 +107,33 @@ def test_fold_and_to_affine_on_host(oracle):
     assert np.array_equal(oracle.g1_projective_to_affine(scaled), pts[1])
 
 
+def test_host_field_arithmetic_against_big_integers():
+    """csrc/host_field.h (the MSM fold and the prover's challenge scalars run on it): the CIOS product and the inversion by
+    the binary extended Euclid (r05; r01 - r04: a^(m - 2)) against Python integers and against the exponentiation, edge values
+    included -- 0, 1, 2, m - 1, small and all-ones-below-m values."""
+    import plonk_prototype_amd as pa
+    lib = pa.load()
+    rng = np.random.default_rng(5)
+    for nl, mod, ops in ((4, B.R_MOD, (0, 2, 4)), (6, B.P_MOD, (1, 3, 5))):
+        Rm = pow(2, 64 * nl, mod)
+        vals = [0, 1, 2, 3, mod - 1, mod - 2, (1 << 64) - 1, 1 << 64, (1 << (64 * nl - 3)) % mod, Rm, pow(Rm, -1, mod)]
+        vals += [int.from_bytes(rng.bytes(8 * nl), "little") % mod for _ in range(400)]
+        a = ints_to_limbs([v * Rm % mod for v in vals], nl)
+        b = ints_to_limbs([(v * 0x9E3779B97F4A7C15 + 7) % mod * Rm % mod for v in vals], nl)
+        out = np.zeros_like(a)
+        u64p = C.POINTER(C.c_uint64)
+        p = lambda x: x.ctypes.data_as(u64p)   # noqa: E731
+        assert lib.pm_test_host_field_op(ops[0], p(a), p(b), p(out), len(vals)) == 0
+        got = limbs_to_ints(out)
+        for v, g in zip(vals, got):
+            assert g == v * ((v * 0x9E3779B97F4A7C15 + 7) % mod) % mod * Rm % mod
+        for op in ops[1:]:
+            assert lib.pm_test_host_field_op(op, p(a), None, p(out), len(vals)) == 0
+            for v, g in zip(vals, limbs_to_ints(out)):
+                assert g == (pow(v, -1, mod) * Rm % mod if v else 0), (nl, op, v)
+    assert lib.pm_test_host_field_op(9, p(a), None, p(out), 1) == -1
+
+
 def test_integration_doc_lists_every_export():
     """INTEGRATION.md's Rust extern block binds exactly the functions the header declares."""
     import re

@@ -52,18 +52,26 @@ def test_dist_prover_equals_single_gpu(ctx, log_n, world, mixed):
             if r & 1:
                 bases.precompute()                      # table and no table side by side
             key.commit(bases)
+            c.comm_stats(reset=True)
             out = _blob(key.prove(bases, wit, pi), key.verifier_key)
+            stats = c.comm_stats()
             again = key.prove(bases, wit, pi, bind_public_inputs=False).to_bytes()
             nbytes = key.device_bytes
             key.free()
-            return out, again, nbytes
+            return out, again, nbytes, stats
         finally:
             c.close()
-    for r, (out, again, nbytes) in enumerate(run_ranks(world, body)):
+    n2 = 1 << (log_n - log_n // 2)
+    for r, (out, again, nbytes, stats) in enumerate(run_ranks(world, body)):
         assert out == single, r
         assert again == upstream, r
-        # per-rank memory: what a rank holds is 1 / world of the single-GPU key's arrays (plus halos and a scalar)
-        assert nbytes <= (160 * n // world + 6 * 4 + 1) * 32, (r, nbytes)
+        # per-rank memory: what a rank holds is 1 / world of the single-GPU key's arrays, plus the stage buffer of the batched
+        # transforms (2 x 20 vectors), the halo rows and a scalar
+        assert nbytes <= (186 * m + 64 * n2 + 8) * 32, (r, nbytes)
+        # exchanges of ONE proof (was 3 per transform x 34 transforms): 3 + 2 for the wires and public inputs,
+        # 3 + 2 for z, 2 for the quotient's way back; the all-to-all of a batch is one call whatever the batch; 9 all-gathers
+        assert stats["alltoall_calls"] == 12, stats
+        assert stats["allgather_calls"] == 9, stats
 
 
 @pytest.mark.parametrize("log_n,world", [(10, 4), (12, 2), (12, 8)])

@@ -286,5 +286,7 @@ def test_dist_prover_world8(ctx, oracle, gk):
     res = run_ranks(world, body, timeout=1500)
     for r, (out, nbytes) in enumerate(res):
         assert out == single, r
-        assert nbytes <= 161 * m * 32, (r, nbytes)       # <= 0.67 GB per rank at 2^20 gates on 8 ranks, 10.7 GB at 2^24
+        # key + workspace + the stage buffer of the batched transforms (2 x 20 vectors): 0.68 GB per rank at 2^20 gates on 8
+        # ranks, 10.9 GB at 2^24 (a single-GPU key at 2^24: ~70 GB)
+        assert nbytes <= (163 * m + 64 * (1 << (gk - gk // 2)) + 8) * 32, (r, nbytes)
     print(f"[n5] 2^{gk} gates on 8 ranks: {res[0][1] / 2**20:.0f} MiB of key + workspace per rank")

@@ -18,4 +18,9 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prv_write -- python3 $PARGS > $OUT/prv_write.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/prv_sq -- python3 $PARGS > $OUT/prv_sq.log 2>&1
 echo "prover pmc rc=$?"
+# the 2^24 shapes (ntt_extra.fwd_inv_2^24, msm_large): FETCH_SIZE and WRITE_SIZE only
+BARGS="$GRAFT_REPO_ROOT/tools/pmc_big.py 24"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/big_fetch -- python3 $BARGS > $OUT/big_fetch.log 2>&1 && \
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/big_write -- python3 $BARGS > $OUT/big_write.log 2>&1
+echo "big pmc rc=$?"
 find $OUT -name "*counter_collection.csv" | head
