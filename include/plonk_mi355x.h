@@ -399,11 +399,11 @@ int pm_plonk_proof_to_bytes(const pm_plonk_proof* proof, uint8_t out[PM_PLONK_PR
  * pm_fr_ntt_fourstep_batch_dev over the ranks (all the polynomials of a round in one sequence of all-to-alls), the 4n-coset
  * work as four size-n sub-coset transforms whose results stay in the block-transposed order (the quotient is pointwise; its
  * one next-row access reads the halo row the transform delivers), and prefix product, openings and Ruffini division are
- * local passes plus one all-gather of per-rank scalars each: 12 all-to-all calls and 9 all-gathers per proof
+ * local passes plus one all-gather of per-rank scalars each: 12 all-to-all calls and 8 all-gathers per proof
  * (pm_comm_stats).  The proof and the verifier key are bit-identical to pm_plonk_prove's on every rank.
  *   allgather: gathers ONE fixed-size message per rank (PM_COMM_MSG_WORDS u64 words, host memory; word 0 = a count,
  *              0 = the abort marker of a rank that gave up) into gathered[world][PM_COMM_MSG_WORDS]; returns 0 on success.
- *              NULL = the context's RCCL communicator (pm_comm_init).  9 per proof (the first an agreement on the
+ *              NULL = the context's RCCL communicator (pm_comm_init).  8 per proof (the first an agreement on the
  *              arguments: public inputs, flags and size must be the same on every rank), 2 + 2 per key.
  *   alltoall:  the callback of pm_fr_ntt_fourstep_dev (device buffers); NULL = the communicator.
  * Inputs are the rank's slices: selector_slices[s] = m = n / world rows of selector s (NULL = identically zero on this

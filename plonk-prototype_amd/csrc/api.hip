@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "context.h"
@@ -137,6 +138,7 @@ extern "C" int pm_init(int device_id, pm_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return PM_ERR_HIP;
   pm_ctx* ctx = new pm_ctx();
   ctx->device = device_id;
+  ctx->marks_on = getenv("PM_HOST_MARKS") != nullptr;
   ctx->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;

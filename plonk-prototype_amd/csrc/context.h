@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -59,6 +60,9 @@ struct pm_ctx {
   pm::DeviceBuffer ntt_tmp[2];
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
   pm::StreamOrder ord_ntt, ord_msm, ord_poly;           // cross-stream ordering of the shared scratch + tables
+  // host timeline (diagnostic, PM_HOST_MARKS=1 in the environment): (label, microseconds) pairs, printed by the prover
+  bool marks_on = false;
+  std::vector<std::pair<const char*, double>> marks;
   unsigned long long stat_alltoall_calls = 0, stat_alltoall_bytes = 0, stat_allgather_calls = 0, stat_transpose_steps = 0;   // pm_comm_stats
   int calls_holding_tables = 0;                         // calls that keep table pointers across unlocked sections (four-step NTT): pm_trim refuses
   // MSM workspaces
@@ -71,7 +75,7 @@ struct pm_ctx {
   pm::DeviceBuffer poly_ws;                             // scratch of the polynomial helpers
   pm::DeviceBuffer poly_tab;                            // power tables of pm_fr_poly_ruffini_dev
   void* msm_host_pinned = nullptr;
-  void* poly_host_pinned = nullptr;                     // 2 x PM_LINCOMB_MAX results of the evaluation batches (poly.hip)
+  void* poly_host_pinned = nullptr;                     // 3 x PM_LINCOMB_MAX results of the evaluation batches (poly.hip)
   size_t msm_host_pinned_bytes = 0;
   // multi-GPU exchange (comm.hip): RCCL communicator of this rank, device and pinned staging buffers
   void* comm = nullptr;
@@ -149,8 +153,12 @@ struct QuotPlanar {
 };
 int plonk_quotient_layout(pm_ctx* ctx, const pm_plonk_quotient_args* args, size_t rows, bool halo, const QuotPlanar* planar,
                           void* d_out, void* hip_stream);
-int poly_evaluate_two(pm_ctx* ctx, uint32_t k1, const void* const* polys1, const uint64_t point1[4], uint64_t* out1, uint32_t k2,
-                      const void* const* polys2, const uint64_t point2[4], uint64_t* out2, size_t n);   // poly.hip
+inline void host_mark(pm_ctx* ctx, const char* label) {
+  if (ctx && ctx->marks_on)
+    ctx->marks.emplace_back(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+int poly_evaluate_groups(pm_ctx* ctx, uint32_t groups, const uint32_t* k, const void* const* const* polys,
+                         const uint64_t* const* points, uint64_t* const* outs, size_t n);   // poly.hip
 int coset_expand(pm_ctx* ctx, const void* const* d_src, uint32_t count, const void* d_gs_pow, size_t m, void* d_out);
 int sigma_evals_from_index(pm_ctx* ctx, const int64_t* idx, size_t count, uint32_t log_n, const uint64_t omega[4],
                            const uint64_t k[3][4], void* d_out);

@@ -252,7 +252,7 @@ PM_DEV void wave_join(const AccArgs& a, size_t wave, bool wave_live, u32 lane, b
 // n, skewed or all-equal scalars) cost up to six additions per wave instead of a pass through a
 // per-thread partial list.  Only what crosses a WAVE boundary is left for the next level: two
 // partial slots per wave.
-__global__ void __launch_bounds__(128, 2) msm_accumulate_l1_kernel(const AccArgs a) {
+__global__ void __launch_bounds__(256, 2) msm_accumulate_l1_kernel(const AccArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   // the number of pairs and the chunk length come from the bucket fill (zero digits are dropped there): the host
   // sized the grid for every digit being non-zero, sparser inputs use shorter chunks on the same grid
@@ -707,9 +707,28 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
   // the length of one thread's chain: the chunk goes down to 12 entries, and to 4 where the runs are that short -- below
   // ~0.6 of a run the in-wave join pays for what the chain saves (profiles/r03_small_msm.txt: batch of four at 2^14,
   // accumulate 434 -> 365 us; at 2^10, 185 -> 108 us)
-  const u32 chunk_lo = (u32)std::min<size_t>(12, std::max<size_t>(4, (6 * avg_run + 9) / 10));
-  const u32 L1 = ctx->opt_msm_chunk ? (u32)ctx->opt_msm_chunk
-                                    : (u32)std::max<size_t>(chunk_lo, (m + rounds * slots - 1) / (rounds * slots));
+  u32 chunk_lo = (u32)std::min<size_t>(12, std::max<size_t>(4, (6 * avg_run + 9) / 10));
+  u32 L1 = ctx->opt_msm_chunk ? (u32)ctx->opt_msm_chunk
+                              : (u32)std::max<size_t>(chunk_lo, (m + rounds * slots - 1) / (rounds * slots));
+  // r05: while the whole grid fits ONE wave per SIMD -- placed exactly, below -- a thread's time is its chain: chunk mixed
+  // additions at a lone wave's ~11.8 us each, then the in-wave join, one general addition (~16.5 us) per doubling of the lanes
+  // a run is spread over.  The chunk that minimises that sum (profiles/r05_small_msm.txt: 2^12 points, one vector: 12 -> 5
+  // entries, accumulate 174 -> 131 us)
+  const size_t lone_waves = (size_t)ctx->num_cus * 4;
+  if (!ctx->opt_msm_chunk) {
+    double best = 1e30;
+    for (u32 L = 2; L <= 16; ++L) {
+      const size_t waves = ((m + L - 1) / L + 63) / 64;
+      if (waves > lone_waves) continue;
+      const double span = (double)avg_run / L + 1.0;
+      const double cost = 11.8 * L + 16.5 * std::ceil(std::log2(span));
+      if (cost < best) {
+        best = cost;
+        L1 = L;
+        chunk_lo = std::min<u32>(chunk_lo, L);
+      }
+    }
+  }
   // Partial lists: every level leaves two slots per WAVE; the deeper levels take one slot per lane, so
   // the list shrinks by 32 per level and ends in a single wave (final level).
   struct Level {
@@ -882,10 +901,23 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
     if (lvl > 0 && last && nthr > 64) return set_err(ctx, PM_ERR_BAD_ARG, "internal: final MSM level wider than a wave");
     {
       ProfScope prof(ctx, st, lvl == 0 ? "msm_accumulate_l1" : "msm_accumulate_ln");
-      if (lvl == 0)
-        hipLaunchKernelGGL(msm_accumulate_l1_kernel, dim3(blocks), dim3(128), 0, st, a);
-      else
+      if (lvl == 0) {
+        // Two waves that share a SIMD run one after the other (oldest first, section 4 of DESIGN.md), and two-wave workgroups
+        // are not spread evenly: a grid of at most one (two) waves per SIMD is launched as four-wave workgroups -- a wave per
+        // SIMD of a CU -- with an LDS request that keeps a second (third) workgroup off the CU.  The kernel uses no LDS.
+        const size_t waves = (nthr + 63) / 64;
+        size_t place_lds = 0;
+        if (waves <= lone_waves) place_lds = 96 * 1024;
+        else if (waves <= 2 * lone_waves) place_lds = 72 * 1024;
+        if (place_lds) {
+          if (int lrc = raise_lds_limit(ctx, (const void*)msm_accumulate_l1_kernel, place_lds)) return lrc;
+          hipLaunchKernelGGL(msm_accumulate_l1_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), place_lds, st, a);
+        } else {
+          hipLaunchKernelGGL(msm_accumulate_l1_kernel, dim3(blocks), dim3(128), 0, st, a);
+        }
+      } else {
         hipLaunchKernelGGL(msm_accumulate_ln_kernel, dim3(blocks), dim3(128), 0, st, a);
+      }
       MSM_STAGE(ctx, st, lvl == 0 ? "accumulate level 1" : "accumulate level n");
     }
     PM_HIP(ctx, hipGetLastError());
@@ -1116,13 +1148,17 @@ int msm_run(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n, const v
                    (char*)ctx->msm_host_pinned + (size_t)i * pin_each, &dummy_pin, &pieces[i]);
   }
   // whatever was enqueued is waited for, also on an error path: the side stream must be idle when the call returns
+  host_mark(ctx, "msm: enqueued");
   hipError_t e0 = hipStreamSynchronize(st), e1 = npieces > 1 ? hipStreamSynchronize(ctx->msm_side) : hipSuccess;
+  host_mark(ctx, "msm: device done");
   if (rc) return rc;
   PM_HIP(ctx, e0);
   PM_HIP(ctx, e1);
   std::vector<XYZZ> totals(batch);
   for (u32 i = 0; i < npieces; ++i) msm_fold(pieces[i], totals.data() + (size_t)i * per_piece);
+  host_mark(ctx, "msm: folded");
   write_projective_batch(out_xyz, totals.data(), batch);
+  host_mark(ctx, "msm: affine");
   return PM_OK;
 }
 

@@ -904,30 +904,31 @@ extern "C" int pm_fr_poly_evaluate_many_dev(pm_ctx* ctx, uint32_t k, const void*
   PM_HIP(ctx, hipStreamSynchronize(st));
   return PM_OK;
 }
-// Two batches at two points (the prover's openings at z and z w) with ONE host synchronisation, on the context's stream.
-int pm::poly_evaluate_two(pm_ctx* ctx, uint32_t k1, const void* const* polys1, const uint64_t point1[4], uint64_t* out1, uint32_t k2,
-                          const void* const* polys2, const uint64_t point2[4], uint64_t* out2, size_t n) {
-  if (!ctx || !polys1 || !polys2 || !point1 || !point2 || !out1 || !out2 || n == 0) return PM_ERR_BAD_ARG;
-  if (k1 == 0 || k2 == 0 || k1 > PM_LINCOMB_MAX || k2 > PM_LINCOMB_MAX) return PM_ERR_BAD_ARG;
+// Up to three batches at their own points (the prover's openings: two groups at z, one at z w) with ONE host
+// synchronisation, on the context's stream.
+int pm::poly_evaluate_groups(pm_ctx* ctx, uint32_t groups, const uint32_t* k, const void* const* const* polys,
+                             const uint64_t* const* points, uint64_t* const* outs, size_t n) {
+  if (!ctx || !k || !polys || !points || !outs || n == 0 || groups == 0 || groups > 3) return PM_ERR_BAD_ARG;
+  for (uint32_t g = 0; g < groups; ++g)
+    if (k[g] == 0 || k[g] > PM_LINCOMB_MAX || !polys[g] || !points[g] || !outs[g]) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   OrderScope order_scope(ctx, ctx->ord_poly, st);
   int rc = order_scope.rc;
   if (rc) return rc;
-  const size_t s1 = eval_slot_bytes(k1, n), s2 = eval_slot_bytes(k2, n);
-  rc = ensure_buffer(ctx, ctx->poly_ws, s1 + s2);
+  size_t off[4] = {0, 0, 0, 0};
+  for (uint32_t g = 0; g < groups; ++g) off[g + 1] = off[g] + eval_slot_bytes(k[g], n);
+  rc = ensure_buffer(ctx, ctx->poly_ws, off[groups]);
   if (rc) return rc;
-  // results through pinned memory: a copy to the caller's pageable arrays would block the host until the first batch is done
-  if (!ctx->poly_host_pinned) PM_HIP(ctx, hipHostMalloc(&ctx->poly_host_pinned, 2 * PM_LINCOMB_MAX * 32, hipHostMallocDefault));
-  uint64_t* h1 = (uint64_t*)ctx->poly_host_pinned;
-  uint64_t* h2 = h1 + 4 * PM_LINCOMB_MAX;
-  rc = eval_enqueue(ctx, st, k1, polys1, n, point1, h1, (char*)ctx->poly_ws.ptr);
-  if (!rc) rc = eval_enqueue(ctx, st, k2, polys2, n, point2, h2, (char*)ctx->poly_ws.ptr + s1);
+  // results through pinned memory: a copy to the caller's pageable arrays would block the host until the batch is done
+  if (!ctx->poly_host_pinned) PM_HIP(ctx, hipHostMalloc(&ctx->poly_host_pinned, 3 * PM_LINCOMB_MAX * 32, hipHostMallocDefault));
+  uint64_t* h = (uint64_t*)ctx->poly_host_pinned;
+  for (uint32_t g = 0; g < groups && !rc; ++g)
+    rc = eval_enqueue(ctx, st, k[g], polys[g], n, points[g], h + 4 * PM_LINCOMB_MAX * g, (char*)ctx->poly_ws.ptr + off[g]);
   if (rc) return rc;
   PM_HIP(ctx, hipStreamSynchronize(st));
-  memcpy(out1, h1, 32 * (size_t)k1);
-  memcpy(out2, h2, 32 * (size_t)k2);
+  for (uint32_t g = 0; g < groups; ++g) memcpy(outs[g], h + 4 * PM_LINCOMB_MAX * g, 32 * (size_t)k[g]);
   return PM_OK;
 }
 

@@ -697,7 +697,19 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
 static int prove_impl(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const Shard& shard, const void* d_witness,
                       const uint64_t* pi_positions, const uint64_t* pi_values, size_t n_pi, uint32_t flags,
                       pm_plonk_proof* out) {
-  return shard_leave(ctx, shard, prove_body(ctx, pk, ck, shard, d_witness, pi_positions, pi_values, n_pi, flags, out));
+  if (ctx && ctx->marks_on) ctx->marks.clear();
+  pm::host_mark(ctx, "prove: start");
+  const int rc = shard_leave(ctx, shard, prove_body(ctx, pk, ck, shard, d_witness, pi_positions, pi_values, n_pi, flags, out));
+  pm::host_mark(ctx, "prove: end");
+  if (ctx && ctx->marks_on && !ctx->marks.empty()) {   // PM_HOST_MARKS=1: where the host's time between the kernels goes
+    const double t0 = ctx->marks.front().second;
+    double prev = t0;
+    for (const auto& mk : ctx->marks) {
+      fprintf(stderr, "[host] %9.1f us  +%7.1f  %s\n", mk.second - t0, mk.second - prev, mk.first);
+      prev = mk.second;
+    }
+  }
+  return rc;
 }
 
 extern "C" int pm_plonk_prove_sharded(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck_slice, size_t first_coefficient,
@@ -757,6 +769,7 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   }
   const HFr one = fone();
   // ---- round 1 --------------------------------------------------------------------------------
+  pm::host_mark(ctx, "round 1");
   PK_TRY(pm_fr_ntt_dev(ctx, d_witness, n, n, pk->coeffs, n, lg, 4, PM_NTT_INVERSE, nullptr));
   // work no challenge depends on goes to the side stream and runs under the MSMs of rounds 1 and 2:
   // the public-input polynomial and the wire polynomials on the 4n coset (round 3 reads them)
@@ -772,6 +785,7 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   PK_TRY(commit_batch(ctx, ck, shard, pk->coeffs, n, n, 4, &out->commitments[0]));
   for (int j = 0; j < 4; ++j) ts.append_commitment(tl::WIRES[j], out->commitments[j]);
   // ---- round 2 --------------------------------------------------------------------------------
+  pm::host_mark(ctx, "round 2");
   const HFr beta = ts.challenge_scalar(tl::BETA);
   ts.append_scalar(tl::BETA, beta);
   const HFr gamma = ts.challenge_scalar(tl::GAMMA);
@@ -797,6 +811,7 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   PK_TRY(commit_batch(ctx, ck, shard, z_coeffs, n, n, 1, &out->commitments[4]));
   ts.append_commitment(tl::PERM, out->commitments[4]);
   // ---- round 3 --------------------------------------------------------------------------------
+  pm::host_mark(ctx, "round 3");
   const HFr alpha = ts.challenge_scalar(tl::ALPHA);
   const HFr range_sep = ts.challenge_scalar(tl::RANGE_SEP);
   const HFr logic_sep = ts.challenge_scalar(tl::LOGIC_SEP);
@@ -838,13 +853,20 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   PK_TRY(commit_batch(ctx, ck, shard, pk->t, n, n, 4, &out->commitments[5]));
   for (int i = 0; i < 4; ++i) ts.append_commitment(tl::QUOTIENT[i], out->commitments[5 + i]);
   // ---- round 4 --------------------------------------------------------------------------------
+  pm::host_mark(ctx, "round 4");
   const HFr zc = ts.challenge_scalar(tl::Z_CHALLENGE), zw = fmul(zc, pk->omega);
   enum { E_A, E_B, E_C, E_D, E_AN, E_BN, E_DN, E_S1, E_S2, E_S3, E_QARITH, E_QC, E_QL, E_QR, E_ZN, E_T, E_R, NEV };
   HFr ev[NEV];
+  // r(z) needs no pass over r: r is a linear combination of key and round polynomials, so r(z) is the same combination of
+  // their values at z -- the ones the proof does not open anyway (q_m, q_o, q_4, z, sigma_4, the widget selectors) ride along
+  // as a second group.  ONE host synchronisation for all openings (r01 - r04: three, with r's own evaluation behind the
+  // linear combination).
+  enum { X_QM, X_QO, X_Q4, X_Z, X_S4, X_RANGE, X_LOGIC, X_FIXED, X_VAR, NX };
+  HFr xv[NX];
   {
-    // 15 polynomials at z and 4 at z w: two batched calls, one host synchronisation each
     const void* at_z[15];
-    u64 out_z[15][4], out_zw[4][4];
+    const void* at_x[NX];
+    u64 out_z[15][4], out_x[NX][4], out_zw[4][4];
     for (int j = 0; j < 4; ++j) at_z[j] = at(pk->coeffs, j * n);
     for (int j = 0; j < 3; ++j) at_z[4 + j] = at(pk->sigma_coeffs, j * n);
     at_z[7] = at(pk->sel_coeffs, Q_ARITH * n);
@@ -852,8 +874,26 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     at_z[9] = at(pk->sel_coeffs, Q_L * n);
     at_z[10] = at(pk->sel_coeffs, Q_R * n);
     for (int i = 0; i < 4; ++i) at_z[11 + i] = at(pk->t, i * n);
+    at_x[X_QM] = at(pk->sel_coeffs, Q_M * n);
+    at_x[X_QO] = at(pk->sel_coeffs, Q_O * n);
+    at_x[X_Q4] = at(pk->sel_coeffs, Q_4 * n);
+    at_x[X_Z] = z_coeffs;
+    at_x[X_S4] = at(pk->sigma_coeffs, 3 * n);
+    uint32_t nx = X_RANGE;
+    const int wsel[4] = {Q_RANGE, Q_LOGIC, Q_FIXED, Q_VAR};
+    int xslot[4] = {-1, -1, -1, -1};
+    for (int w = 0; w < 4; ++w)
+      if (!pk->sel_zero[wsel[w]]) {
+        xslot[w] = (int)nx;
+        at_x[nx++] = at(pk->sel_coeffs, wsel[w] * n);
+      }
     const void* at_zw[4] = {at(pk->coeffs, 0), at(pk->coeffs, n), at(pk->coeffs, 3 * n), z_coeffs};
-    PK_TRY(pm::poly_evaluate_two(ctx, 15, at_z, zc.l, &out_z[0][0], 4, at_zw, zw.l, &out_zw[0][0], n));   // one synchronisation
+    const uint32_t gk[3] = {15, nx, 4};
+    const void* const* gp[3] = {at_z, at_x, at_zw};
+    const uint64_t* gpt[3] = {zc.l, zc.l, zw.l};
+    uint64_t* gout[3] = {&out_z[0][0], &out_x[0][0], &out_zw[0][0]};
+    PK_TRY(pm::poly_evaluate_groups(ctx, 3, gk, gp, gpt, gout, n));
+    pm::host_mark(ctx, "openings at z, z w");
     for (int j = 0; j < 4; ++j) ev[E_A + j] = get(out_z[j]);
     for (int j = 0; j < 3; ++j) ev[E_S1 + j] = get(out_z[4 + j]);
     ev[E_QARITH] = get(out_z[7]);
@@ -866,6 +906,8 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     ev[E_ZN] = get(out_zw[3]);
     const HFr zn_ = fpow(zc, n);
     ev[E_T] = fadd(get(out_z[11]), fmul(zn_, fadd(get(out_z[12]), fmul(zn_, fadd(get(out_z[13]), fmul(zn_, get(out_z[14])))))));
+    for (int j = 0; j < X_RANGE; ++j) xv[j] = get(out_x[j]);
+    for (int w = 0; w < 4; ++w) xv[X_RANGE + w] = xslot[w] >= 0 ? get(out_x[xslot[w]]) : pm::host::zero<4>();
   }
   const HFr zn = fpow(zc, n);
   const HFr &a_ = ev[E_A], &b_ = ev[E_B], &c_ = ev[E_C], &d_ = ev[E_D], &s1 = ev[E_S1], &s2 = ev[E_S2], &s3 = ev[E_S3],
@@ -883,27 +925,29 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
     const void* lin_v[12];
     u64 lin_c[12][4];
     uint32_t k = 0;
-    auto term = [&](const void* v, const HFr& c) {
+    HFr r_z = pm::host::zero<4>();   // r(z) = sum of coefficient x value at z, term by term
+    auto term = [&](const void* v, const HFr& c, const HFr& value_at_z) {
       lin_v[k] = v;
       put(lin_c[k], c);
+      r_z = fadd(r_z, fmul(c, value_at_z));
       ++k;
     };
     // arithmetic: q_arith(z) (a b q_m + a q_l + b q_r + c q_o + d q_4 + q_c)
-    term(at(pk->sel_coeffs, Q_M * n), fmul(qar, fmul(a_, b_)));
-    term(at(pk->sel_coeffs, Q_L * n), fmul(qar, a_));
-    term(at(pk->sel_coeffs, Q_R * n), fmul(qar, b_));
-    term(at(pk->sel_coeffs, Q_O * n), fmul(qar, c_));
-    term(at(pk->sel_coeffs, Q_4 * n), fmul(qar, d_));
-    term(at(pk->sel_coeffs, Q_C * n), qar);
-    if (!pk->sel_zero[Q_RANGE]) term(at(pk->sel_coeffs, Q_RANGE * n), widget_range(range_sep, re));
-    if (!pk->sel_zero[Q_LOGIC]) term(at(pk->sel_coeffs, Q_LOGIC * n), widget_logic(logic_sep, re));
-    if (!pk->sel_zero[Q_FIXED]) term(at(pk->sel_coeffs, Q_FIXED * n), widget_fixed(fixed_sep, re));
-    if (!pk->sel_zero[Q_VAR]) term(at(pk->sel_coeffs, Q_VAR * n), widget_var(var_sep, re));
-    term(z_coeffs, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)));
-    term(at(pk->sigma_coeffs, 3 * n), fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next)));
-    PK_TRY(pm_fr_lincomb_dev(ctx, k, lin_v, &lin_c[0][0], n, pk->r, nullptr));
+    term(at(pk->sel_coeffs, Q_M * n), fmul(qar, fmul(a_, b_)), xv[X_QM]);
+    term(at(pk->sel_coeffs, Q_L * n), fmul(qar, a_), ev[E_QL]);
+    term(at(pk->sel_coeffs, Q_R * n), fmul(qar, b_), ev[E_QR]);
+    term(at(pk->sel_coeffs, Q_O * n), fmul(qar, c_), xv[X_QO]);
+    term(at(pk->sel_coeffs, Q_4 * n), fmul(qar, d_), xv[X_Q4]);
+    term(at(pk->sel_coeffs, Q_C * n), qar, ev[E_QC]);
+    if (!pk->sel_zero[Q_RANGE]) term(at(pk->sel_coeffs, Q_RANGE * n), widget_range(range_sep, re), xv[X_RANGE]);
+    if (!pk->sel_zero[Q_LOGIC]) term(at(pk->sel_coeffs, Q_LOGIC * n), widget_logic(logic_sep, re), xv[X_LOGIC]);
+    if (!pk->sel_zero[Q_FIXED]) term(at(pk->sel_coeffs, Q_FIXED * n), widget_fixed(fixed_sep, re), xv[X_FIXED]);
+    if (!pk->sel_zero[Q_VAR]) term(at(pk->sel_coeffs, Q_VAR * n), widget_var(var_sep, re), xv[X_VAR]);
+    term(z_coeffs, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)), xv[X_Z]);
+    term(at(pk->sigma_coeffs, 3 * n), fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next)), xv[X_S4]);
+    PK_TRY(pm_fr_lincomb_dev(ctx, k, lin_v, &lin_c[0][0], n, pk->r, nullptr));   // r itself: round 5 divides it
+    ev[E_R] = r_z;
   }
-  PK_TRY(pm_fr_poly_evaluate_dev(ctx, pk->r, n, zc.l, ev[E_R].l, nullptr));
   static_assert(NEV == 17, "tl::EVALS lists the evaluations in this enum's order");
   for (int i = 0; i < NEV; ++i) {
     ts.append_scalar(tl::EVALS[i], ev[i]);

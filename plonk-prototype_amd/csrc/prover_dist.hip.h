@@ -20,7 +20,7 @@
 // 3 + 2 (wires and public inputs: to coefficients, onto the coset) + 3 + 2 (z) + 2 (quotient) = 12 all-to-all calls, where
 // r04 made 3 per transform x 34 transforms = 102 (pm_comm_stats counts them).  Prefix product, openings and Ruffini division
 // are local passes plus one fixed-size all-gather of per-rank scalars each.  Every exchange besides the all-to-all is
-// the SAME 2312-byte message all-gather as the sharded prover's (count word 0 = abort marker): 9 per proof, the first an
+// the SAME 2312-byte message all-gather as the sharded prover's (count word 0 = abort marker): 8 per proof, the first an
 // agreement on the arguments: a rank whose arguments are bad meets its peers there with the marker.  (A rank that fails
 // LATER, between two all-to-alls -- a HIP error, an allocation -- returns its error; its peers see the marker at their next
 // all-gather but cannot see it inside an all-to-all: treat such an error as fatal for the group.)
@@ -582,10 +582,15 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
   enum { E_A, E_B, E_C, E_D, E_AN, E_BN, E_DN, E_S1, E_S2, E_S3, E_QARITH, E_QC, E_QL, E_QR, E_ZN, E_T, E_R, NEV };
   HFr ev[NEV];
   const HFr zc_lo = fpow64(zc, lo), zw_lo = fpow64(zw, lo);
+  // r(z) is the linear combination of the values at z of the polynomials r combines (prover.hip, round 4): the ones the proof
+  // does not open ride along as a second group -- one host synchronisation and ONE exchange for all openings, none for r
+  enum { X_QM, X_QO, X_Q4, X_Z, X_S4, X_RANGE, X_LOGIC, X_FIXED, X_VAR, NX };
+  HFr xv[NX];
   {
     // openings: every rank evaluates its coefficient slice (sum_i c_{lo + i} z^i), scales by z^lo, and the sums go round
     const void* at_z[15];
-    u64 out_z[15][4], out_zw[4][4];
+    const void* at_x[NX];
+    u64 out_z[15][4], out_x[NX][4], out_zw[4][4];
     for (int j = 0; j < 4; ++j) at_z[j] = at(pk->coeffs, j * m);
     for (int j = 0; j < 3; ++j) at_z[4 + j] = at(pk->sigma_coeffs, j * m);
     at_z[7] = at(pk->sel_coeffs, Q_ARITH * m);
@@ -593,17 +598,36 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
     at_z[9] = at(pk->sel_coeffs, Q_L * m);
     at_z[10] = at(pk->sel_coeffs, Q_R * m);
     for (int i = 0; i < 4; ++i) at_z[11 + i] = at(pk->t, i * m);
+    at_x[X_QM] = at(pk->sel_coeffs, Q_M * m);
+    at_x[X_QO] = at(pk->sel_coeffs, Q_O * m);
+    at_x[X_Q4] = at(pk->sel_coeffs, Q_4 * m);
+    at_x[X_Z] = z_coeffs;
+    at_x[X_S4] = at(pk->sigma_coeffs, 3 * m);
+    uint32_t nx = X_RANGE;
+    const int wsel[4] = {Q_RANGE, Q_LOGIC, Q_FIXED, Q_VAR};
+    int xslot[4] = {-1, -1, -1, -1};
+    for (int w = 0; w < 4; ++w)
+      if (!pk->sel_zero[wsel[w]]) {
+        xslot[w] = (int)nx;
+        at_x[nx++] = at(pk->sel_coeffs, wsel[w] * m);
+      }
     const void* at_zw[4] = {at(pk->coeffs, 0), at(pk->coeffs, m), at(pk->coeffs, 3 * m), z_coeffs};
-    PK_TRY(pm::poly_evaluate_two(ctx, 15, at_z, zc.l, &out_z[0][0], 4, at_zw, zw.l, &out_zw[0][0], m));   // one synchronisation
-    HFr part[19];
+    const uint32_t gk[3] = {15, nx, 4};
+    const void* const* gp[3] = {at_z, at_x, at_zw};
+    const uint64_t* gpt[3] = {zc.l, zc.l, zw.l};
+    uint64_t* gout[3] = {&out_z[0][0], &out_x[0][0], &out_zw[0][0]};
+    PK_TRY(pm::poly_evaluate_groups(ctx, 3, gk, gp, gpt, gout, m));
+    constexpr uint32_t NP = 15 + 4 + NX;
+    HFr part[NP];
     for (int j = 0; j < 15; ++j) part[j] = fmul(get(out_z[j]), zc_lo);
     for (int j = 0; j < 4; ++j) part[15 + j] = fmul(get(out_zw[j]), zw_lo);
+    for (uint32_t j = 0; j < NX; ++j) part[19 + j] = j < nx ? fmul(get(out_x[j]), zc_lo) : pm::host::zero<4>();
     std::vector<HFr> all;
-    PK_TRY(dist_scalars(ctx, D, part, 19, all));
-    HFr sum[19];
-    for (int j = 0; j < 19; ++j) {
+    PK_TRY(dist_scalars(ctx, D, part, NP, all));
+    HFr sum[NP];
+    for (uint32_t j = 0; j < NP; ++j) {
       sum[j] = pm::host::zero<4>();
-      for (uint32_t r = 0; r < W; ++r) sum[j] = fadd(sum[j], all[(size_t)r * 19 + j]);
+      for (uint32_t r = 0; r < W; ++r) sum[j] = fadd(sum[j], all[(size_t)r * NP + j]);
     }
     for (int j = 0; j < 4; ++j) ev[E_A + j] = sum[j];
     for (int j = 0; j < 3; ++j) ev[E_S1 + j] = sum[4 + j];
@@ -617,6 +641,8 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
     ev[E_ZN] = sum[18];
     const HFr zn_ = fpow(zc, n);
     ev[E_T] = fadd(sum[11], fmul(zn_, fadd(sum[12], fmul(zn_, fadd(sum[13], fmul(zn_, sum[14]))))));
+    for (int j = 0; j < X_RANGE; ++j) xv[j] = sum[19 + j];
+    for (int w = 0; w < 4; ++w) xv[X_RANGE + w] = xslot[w] >= 0 ? sum[19 + xslot[w]] : pm::host::zero<4>();
   }
   const HFr zn = fpow(zc, n);
   const HFr &a_ = ev[E_A], &b_ = ev[E_B], &c_ = ev[E_C], &d_ = ev[E_D], &s1 = ev[E_S1], &s2 = ev[E_S2], &s3 = ev[E_S3],
@@ -634,33 +660,27 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
     const void* lin_v[12];
     u64 lin_c[12][4];
     uint32_t k = 0;
-    auto term = [&](const void* v, const HFr& c) {
+    HFr r_z = pm::host::zero<4>();
+    auto term = [&](const void* v, const HFr& c, const HFr& value_at_z) {
       lin_v[k] = v;
       put(lin_c[k], c);
+      r_z = fadd(r_z, fmul(c, value_at_z));
       ++k;
     };
-    term(at(pk->sel_coeffs, Q_M * m), fmul(qar, fmul(a_, b_)));
-    term(at(pk->sel_coeffs, Q_L * m), fmul(qar, a_));
-    term(at(pk->sel_coeffs, Q_R * m), fmul(qar, b_));
-    term(at(pk->sel_coeffs, Q_O * m), fmul(qar, c_));
-    term(at(pk->sel_coeffs, Q_4 * m), fmul(qar, d_));
-    term(at(pk->sel_coeffs, Q_C * m), qar);
-    if (!pk->sel_zero[Q_RANGE]) term(at(pk->sel_coeffs, Q_RANGE * m), widget_range(range_sep, re));
-    if (!pk->sel_zero[Q_LOGIC]) term(at(pk->sel_coeffs, Q_LOGIC * m), widget_logic(logic_sep, re));
-    if (!pk->sel_zero[Q_FIXED]) term(at(pk->sel_coeffs, Q_FIXED * m), widget_fixed(fixed_sep, re));
-    if (!pk->sel_zero[Q_VAR]) term(at(pk->sel_coeffs, Q_VAR * m), widget_var(var_sep, re));
-    term(z_coeffs, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)));
-    term(at(pk->sigma_coeffs, 3 * m), fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next)));
+    term(at(pk->sel_coeffs, Q_M * m), fmul(qar, fmul(a_, b_)), xv[X_QM]);
+    term(at(pk->sel_coeffs, Q_L * m), fmul(qar, a_), ev[E_QL]);
+    term(at(pk->sel_coeffs, Q_R * m), fmul(qar, b_), ev[E_QR]);
+    term(at(pk->sel_coeffs, Q_O * m), fmul(qar, c_), xv[X_QO]);
+    term(at(pk->sel_coeffs, Q_4 * m), fmul(qar, d_), xv[X_Q4]);
+    term(at(pk->sel_coeffs, Q_C * m), qar, ev[E_QC]);
+    if (!pk->sel_zero[Q_RANGE]) term(at(pk->sel_coeffs, Q_RANGE * m), widget_range(range_sep, re), xv[X_RANGE]);
+    if (!pk->sel_zero[Q_LOGIC]) term(at(pk->sel_coeffs, Q_LOGIC * m), widget_logic(logic_sep, re), xv[X_LOGIC]);
+    if (!pk->sel_zero[Q_FIXED]) term(at(pk->sel_coeffs, Q_FIXED * m), widget_fixed(fixed_sep, re), xv[X_FIXED]);
+    if (!pk->sel_zero[Q_VAR]) term(at(pk->sel_coeffs, Q_VAR * m), widget_var(var_sep, re), xv[X_VAR]);
+    term(z_coeffs, fadd(fmul(alpha, ident), fmul(alpha2, l1_z)), xv[X_Z]);
+    term(at(pk->sigma_coeffs, 3 * m), fneg(fmul(fmul(fmul(alpha, copy3), beta), z_next)), xv[X_S4]);
     PK_TRY(pm_fr_lincomb_dev(ctx, k, lin_v, &lin_c[0][0], m, pk->r, nullptr));
-  }
-  {
-    HFr part;
-    PK_TRY(pm_fr_poly_evaluate_dev(ctx, pk->r, m, zc.l, part.l, nullptr));
-    part = fmul(part, zc_lo);
-    std::vector<HFr> all;
-    PK_TRY(dist_scalars(ctx, D, &part, 1, all));
-    ev[E_R] = pm::host::zero<4>();
-    for (uint32_t r = 0; r < W; ++r) ev[E_R] = fadd(ev[E_R], all[r]);
+    ev[E_R] = r_z;
   }
   static_assert(NEV == 17, "tl::EVALS lists the evaluations in this enum's order");
   for (int i = 0; i < NEV; ++i) {
@@ -736,6 +756,6 @@ extern "C" int pm_plonk_prove_dist(pm_ctx* ctx, const pm_dist* dist, pm_dist_key
   if (!ctx || !dist) return PM_ERR_BAD_ARG;
   Dist D;
   D.d = *dist;
-  D.expect = 9;
+  D.expect = 8;
   return dist_leave(ctx, D, prove_dist_body(ctx, D, key, ck_slice, d_witness_slices, pi_positions, pi_values, n_pi, flags, out));
 }

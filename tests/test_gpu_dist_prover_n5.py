@@ -69,9 +69,9 @@ def test_dist_prover_equals_single_gpu(ctx, log_n, world, mixed):
         # transforms (2 x 20 vectors), the halo rows and a scalar
         assert nbytes <= (186 * m + 64 * n2 + 8) * 32, (r, nbytes)
         # exchanges of ONE proof (was 3 per transform x 34 transforms): 3 + 2 for the wires and public inputs,
-        # 3 + 2 for z, 2 for the quotient's way back; the all-to-all of a batch is one call whatever the batch; 9 all-gathers
+        # 3 + 2 for z, 2 for the quotient's way back; the all-to-all of a batch is one call whatever the batch; 8 all-gathers
         assert stats["alltoall_calls"] == 12, stats
-        assert stats["allgather_calls"] == 9, stats
+        assert stats["allgather_calls"] == 8, stats
 
 
 @pytest.mark.parametrize("log_n,world", [(10, 4), (12, 2), (12, 8)])

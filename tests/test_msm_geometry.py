@@ -122,7 +122,9 @@ def test_sizing_pass_accepts_every_shape_and_stays_proportionate(lib):
                     assert 16 * pairs + 256 * buckets <= ws <= 21 * pairs + 32 * n * batch + 300 * buckets + (64 << 20), tag
                     # 7 + 5 levels sequences of <= 4 entries per set, or one record per set when the device applies the weights itself
                     assert 256 * batch * g["nsets"] <= pinned <= 22 * 4 * 256 * batch * g["nsets"], tag
-                    assert ws >= 0.9 * prev or not table_c, tag        # (the chunk length steps with the grid's rounds)
+                    # (the chunk length steps with the grid's rounds, and -- r05 -- small grids take the chunk a latency model picks:
+                    # the per-thread head slots follow the thread count)
+                    assert ws >= 0.6 * prev or not table_c, tag
                     prev = ws
                     n_checked += 1
     assert n_checked > 1500
