@@ -907,8 +907,11 @@ static int msm_piece(pm_ctx* ctx, const pm_bases* bases, size_t offset, size_t n
         // SIMD of a CU -- with an LDS request that keeps a second (third) workgroup off the CU.  The kernel uses no LDS.
         const size_t waves = (nthr + 63) / 64;
         size_t place_lds = 0;
-        if (waves <= lone_waves) place_lds = 96 * 1024;
-        else if (waves <= 2 * lone_waves) place_lds = 72 * 1024;
+        // (just over a half / a third of the CU's 160 KB: what is left -- 79 KB / 52 KB -- still takes the workgroups of the
+        // prover's side stream, the coset transforms that run beside the commitments of rounds 1 and 2; with 96 / 72 KB those
+        // kept accumulate workgroups waiting for a CU: 2^16-gate proofs took 4.13 ms or 4.47 ms, at random)
+        if (waves <= lone_waves) place_lds = 81 * 1024;
+        else if (waves <= 2 * lone_waves) place_lds = 54 * 1024;
         if (place_lds) {
           if (int lrc = raise_lds_limit(ctx, (const void*)msm_accumulate_l1_kernel, place_lds)) return lrc;
           hipLaunchKernelGGL(msm_accumulate_l1_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), place_lds, st, a);
