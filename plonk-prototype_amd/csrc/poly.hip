@@ -341,6 +341,9 @@ PM_DEV u32 pp_fetch(const u32* slot, Fr& v) {   // -> the tag, 0 = not there yet
   return lo == hi ? lo : 0u;
 }
 constexpr u32 PP_AHEAD = 4;   // look-back rounds whose records are requested together
+// TW: the vector holds device-form 48-byte entries (an inner level of the chunked scan: the chunk totals) instead of canonical
+// elements, read and written per thread (no LDS staging), and the exclusive products go back in device form -- in place.
+template <bool TW>
 __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_t n, u32x4* out, u32* ctl, u32 tiles) {
   extern __shared__ u32x4 sc_lds[];
   __shared__ u32 sh[4 * 9 + 9];
@@ -353,15 +356,19 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
   if (tile >= tiles) return;
   const size_t tile0 = (size_t)tile * SC_TILE;
   u32 w[SC_K][8];
-  tile_load(in, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
+  if (!TW) tile_load(in, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
   const size_t lo = tile0 + (size_t)t * SC_K;
   const Fr one = fe_one<FrP>();
   // 1 the thread's product, then the inclusive scan over the workgroup's threads (as pp_base_kernel)
   Fr a[SC_K];
   Fr tot = one;
+  if (TW) {
+#pragma unroll
+    for (int k = 0; k < SC_K; ++k) a[k] = lo + k < n ? ld_tw(in, lo + k) : one;   // all loads in flight at once
+  }
 #pragma unroll
   for (int k = 0; k < SC_K; ++k) {
-    a[k] = lo + k < n ? abi_to_dev(fe_unpack<FrP>(w[k])) : one;
+    if (!TW) a[k] = lo + k < n ? abi_to_dev(fe_unpack<FrP>(w[k])) : one;
     tot = k == 0 ? a[0] : fe_mul<FrP>(tot, a[k]);
   }
   Fr inc = tot;
@@ -440,6 +447,15 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
   Fr run;
 #pragma unroll
   for (int i = 0; i < 9; ++i) run.l[i] = sh[36 + i];
+  if (TW) {
+    run = fe_mul<FrP>(run, excl);
+#pragma unroll
+    for (int k = 0; k < SC_K; ++k) {
+      if (lo + k < n) st_tw(out, lo + k, run);
+      run = fe_mul<FrP>(run, a[k]);
+    }
+    return;
+  }
   run = fe_mul<FrP>(fe_mul<FrP>(run, excl), fe_pow2<FrP, 256>());   // device form -> ABI form; ABI x device stays ABI
 #pragma unroll
   for (int k = 0; k < SC_K; ++k) {
@@ -1048,12 +1064,12 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
   if (!d_in || !d_out) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  // One pass (pp_lookback_kernel) while every tile is resident at once (four workgroups per CU): 2^16 51.8 -> 31.9 us,
+  // One pass (pp_lookback_kernel) while every tile is resident at once (r05: up to two tiles per CU; r03 - r04: four): 2^16 51.8 -> 31.9 us,
   // 2^18 71.4 -> 35.6, 2^20 93.5 -> 61.7, 2^21 135 -> 109; with a second generation of tiles the walk back over the
   // ~1000 tiles in flight (all in the same phase: none has its inclusive product yet) is paid per generation and the
   // three-stage scan below is as fast (2^22: 195 vs 197 us) or faster (2^24: 708 vs 584 us) -- profiles/r03_poly_rows.txt.
   // opt_poly_lookback: 0 = never, 1 = by this rule, 2 = whenever there is more than one tile (tests).
-  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 4 * (size_t)ctx->num_cus;
+  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 2 * (size_t)ctx->num_cus;
   if (ctx->opt_poly_lookback && n > (size_t)SC_TILE && n <= lookback_max) {
     // ticket + status + two 48-byte values per tile, zeroed per call
     const u32 tiles = (u32)((n + SC_TILE - 1) / SC_TILE);
@@ -1063,24 +1079,39 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
     if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, ctl_bytes);
     if (rc) return rc;
     const size_t lds = (size_t)SC_LDS_SLOTS * 16;
-    const void* fn = (const void*)pp_lookback_kernel;
+    const void* fn = (const void*)pp_lookback_kernel<false>;
     if (int lrc = raise_lds_limit(ctx, fn, lds)) return lrc;
     ProfScope prof(ctx, st, "fr_prefix_product");
     PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, ctl_bytes, st));
-    hipLaunchKernelGGL(pp_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_in, n, (u32x4*)d_out,
+    hipLaunchKernelGGL(pp_lookback_kernel<false>, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_in, n, (u32x4*)d_out,
                        (u32*)ctx->poly_ws.ptr, tiles);
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
   }
+  // r05: the chunked scan above 2^21 keeps its two level-0 passes (1 product per element each) but stops descending at the first
+  // level whose tiles are all resident at once and scans THAT level with one look-back launch (pp_lookback_kernel<true>: the
+  // regime where the one-pass form wins) instead of three more levels of totals / base / replay launches, each the latency of
+  // 8 dependent products: 2^21 109 (one pass) -> 99 us, 2^22 196 -> 160 us (0.171 -> 0.210 of HBM), 2^23 337 -> 315, 2^24 593 -> 569
+  // (profiles/r05_poly_rows.txt); the one-pass form keeps the sizes up to 2 tiles per CU (2^20: 62 us)
+  const size_t tw_resident = (size_t)SC_TILE * 2 * (size_t)ctx->num_cus;   // two workgroups per CU at this kernel's register count
   std::vector<size_t> sz;
   sz.push_back(n);
-  while (sz.back() > (size_t)SC_BASE) sz.push_back((sz.back() + SC_K - 1) / SC_K);
+  bool top_lookback = false;
+  while (sz.back() > (size_t)SC_BASE) {
+    sz.push_back((sz.back() + SC_K - 1) / SC_K);
+    if (ctx->opt_poly_lookback && sz.back() > (size_t)SC_BASE && sz.back() <= tw_resident) {
+      top_lookback = true;
+      break;
+    }
+  }
   if (sz.size() == 1) sz.push_back((n + SC_K - 1) / SC_K);
   size_t tot_entries = 0;
   for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
+  const u32 top_tiles = top_lookback ? (u32)((sz.back() + SC_TILE - 1) / SC_TILE) : 0u;
+  const size_t lvl_bytes = (tot_entries * 48 + 64 + 255) / 256 * 256, ctl_bytes = top_lookback ? 64 + (size_t)top_tiles * 48 : 0;
   OrderScope order_scope(ctx, ctx->ord_poly, st);
   int rc = order_scope.rc;
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, tot_entries * 48 + 64);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, lvl_bytes + ctl_bytes);
   if (rc) return rc;
   std::vector<u32x4*> lvl(sz.size());
   {
@@ -1104,7 +1135,14 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
       hipLaunchKernelGGL(pp_totals_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)lvl[i], sz[i], lvl[i + 1],
                          sz[i + 1]);
   }
-  hipLaunchKernelGGL(pp_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last]);
+  if (top_lookback) {
+    u32* ctl = (u32*)((char*)ctx->poly_ws.ptr + lvl_bytes);
+    PM_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, st));
+    hipLaunchKernelGGL(pp_lookback_kernel<true>, dim3(top_tiles), dim3(256), 0, st, (const u32x4*)lvl[last], sz[last], lvl[last], ctl,
+                       top_tiles);
+  } else {
+    hipLaunchKernelGGL(pp_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last]);
+  }
   for (size_t i = last; i-- > 0;) {
     const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
     if (i == 0)

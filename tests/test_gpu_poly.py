@@ -78,11 +78,14 @@ def test_batch_inverse(ctx, oracle, n):
     assert np.array_equal(prod[nz], np.broadcast_to(one, (int(nz.sum()), 4))) and not prod[~nz].any()
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 4096, 4097, 5000, 1 << 16, (1 << 20) + 3, (1 << 21) + (1 << 19)])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 4096, 4097, 5000, 1 << 16, (1 << 20) + 3, (1 << 21) + (1 << 19),
+                               (1 << 22) + 9, (1 << 23) + 3])
 def test_prefix_product(ctx, oracle, n):
+    """(above 2^21 the library's choice is the chunked scan with ONE look-back launch over the first inner level that is
+    resident at once -- level 1 up to 2^23, level 2 beyond: r05)"""
     a = oracle.fr_sample(21 + n, n)
     if n > 6000:
-        a[5000] = 0                                       # everything after a zero factor is zero
+        a[5000 if n < (1 << 20) else n - 777] = 0         # everything after a zero factor is zero
     want = oracle.fr_prefix_product(a)
     try:
         for mode in (1, 0, 2):                            # the library's choice, the three-stage scan, the one-pass look-back

@@ -1,7 +1,7 @@
 #!/bin/bash
 # After `gpurun -- bash tools/final_gpu_run.sh TAG`: copy what is judged from gpurun_out/TAG into profiles/ (newest file of each kind:
 # gpurun merges runs into the same directories).  usage: bash tools/refresh_profiles.sh [TAG] [ROUND]
-TAG=${1:-r04z}; R=${2:-r04}
+TAG=${1:-r05z}; R=${2:-r05}
 O=gpurun_out/$TAG
 for p in headline:stats_headline bench:stats msm:stats_msm msm24:stats_msm24; do
   n=${p%%:*}; d=${p##*:}
@@ -10,6 +10,9 @@ done
 cp $O/bench.json profiles/${R}_bench.json
 cp $O/pmc_summary.json profiles/${R}_pmc_summary.json
 cp $O/pmc_prover_summary.json profiles/${R}_pmc_prover_summary.json
+cp $O/pmc_big_summary.json profiles/${R}_pmc_big_summary.json
+cp $O/small_proofs.txt profiles/${R}_small_proofs.txt
+cp $O/proof_latency_trace.txt profiles/${R}_proof_latency_trace.txt
 cp $O/pytest_gpu.txt profiles/${R}_pytest_gpu.txt
 cp $O/sort_bench.txt profiles/${R}_sort_bench.txt
 cp $O/poly_rows.txt profiles/${R}_poly_rows.txt
