@@ -607,6 +607,9 @@ struct RufLook {
   u32 zt[9];       // z^SC_TILE
   u32 zt64[9];     // z^(64 SC_TILE)
 };
+// TW (r05): the vector is an INNER level of the chunked scan -- ABI-form 48-byte entries T_k in forward order, multiplier z = this
+// level's z^(SC_K^level) -- scanned in place: T_k <- y_{k-1}, the carry INTO chunk k (what ruf_base_kernel leaves).
+template <bool TW>
 __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, u32x4* out,
                                                             u32* ctl, u32 tiles, const RufLook lk) {
   extern __shared__ u32x4 sc_lds[];
@@ -620,15 +623,19 @@ __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, 
   if (tile >= tiles) return;
   const size_t tile0 = (size_t)tile * SC_TILE;
   u32 w[SC_K][8];
-  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+  if (!TW) tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
   const size_t lo = tile0 + (size_t)t * SC_K;
   const Fr z = fr_limbs(lk.z), one = fe_one<FrP>(), zero = fe_zero<FrP>();
   // 1 the thread's chunk from a zero start (a short last chunk is padded at the end with zeros: y -> z y)
   Fr d[SC_K];
   Fr y = zero;
+  if (TW) {
+#pragma unroll
+    for (int k = 0; k < SC_K; ++k) d[k] = lo + k < m ? ld_tw(coeffs, lo + k) : zero;   // all loads in flight at once
+  }
 #pragma unroll
   for (int k = 0; k < SC_K; ++k) {
-    d[k] = lo + k < m ? fe_unpack<FrP>(w[k]) : zero;
+    if (!TW) d[k] = lo + k < m ? fe_unpack<FrP>(w[k]) : zero;
     y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
   }
   // 2 inclusive scan over the threads of the wave: Y_t = y_t + z^SC_K Y_{t-1}; beside it the powers z^(SC_K (lane + 1))
@@ -723,6 +730,14 @@ __global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, 
 #pragma unroll
   for (int i = 0; i < 9; ++i) C.l[i] = sh[36 + i];
   y = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(C, mult)));
+  if (TW) {
+#pragma unroll
+    for (int k = 0; k < SC_K; ++k) {
+      if (lo + k < m) st_tw(out, lo + k, y);
+      y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < SC_K; ++k) {
     if (lo + k < m) {
@@ -977,8 +992,9 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
   }
   // one pass (see pm_fr_prefix_product_dev) while the tiles are few: this recurrence costs ~4.5 products per element in one
   // pass (the powers of z every thread and every look-back lane needs) against 2.2 in three stages -- 2^16 69.7 -> 44.5 us,
-  // 2^18 87.2 -> 48.6, 2^20 112 -> 101, but 2^21 155 -> 191: up to 2.5 tiles per CU (profiles/r03_poly_rows.txt)
-  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 5 * (size_t)ctx->num_cus / 2;
+  // 2^18 87.2 -> 48.6, 2^19 67 -> 51, but 2^20 79 (the r05 hybrid below) against 94, 2^21 109 against 191: up to 1.5 tiles per CU
+  // (profiles/r03_poly_rows.txt, profiles/r05_poly_rows.txt)
+  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 3 * (size_t)ctx->num_cus / 2;
   if (ctx->opt_poly_lookback && m > (size_t)SC_TILE && m <= lookback_max) {
     const u32 tiles = (u32)((m + SC_TILE - 1) / SC_TILE);
     const size_t head = 64 + (size_t)tiles * 48;
@@ -992,25 +1008,37 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
     to_limbs29(lk2.zt, zt);
     to_limbs29(lk2.zt64, hfr_pow_u64(zt, 64));
     const size_t lds = (size_t)SC_LDS_SLOTS * 16;
-    const void* fn = (const void*)ruf_lookback_kernel;
+    const void* fn = (const void*)ruf_lookback_kernel<false>;
     if (int lrc = raise_lds_limit(ctx, fn, lds)) return lrc;
     ProfScope prof(ctx, st, "fr_poly_ruffini");
     PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, head, st));
-    hipLaunchKernelGGL(ruf_lookback_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (u32x4*)d_out,
+    hipLaunchKernelGGL(ruf_lookback_kernel<false>, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (u32x4*)d_out,
                        (u32*)ctx->poly_ws.ptr, tiles, lk2);
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
   }
   // level sizes: m, ceil(m / K), ... until one workgroup holds the level
+  // r05 (as for the prefix product): the descent stops at the first inner level whose tiles are all resident at once (this kernel:
+  // one workgroup per CU) and that level is scanned by ONE look-back launch (ruf_lookback_kernel<true>)
+  const size_t tw_resident = (size_t)SC_TILE * (size_t)ctx->num_cus;
   std::vector<size_t> sz;
   sz.push_back(m);
-  while (sz.back() > (size_t)SC_BASE) sz.push_back((sz.back() + SC_K - 1) / SC_K);
+  bool top_lookback = false;
+  while (sz.back() > (size_t)SC_BASE) {
+    sz.push_back((sz.back() + SC_K - 1) / SC_K);
+    if (ctx->opt_poly_lookback && sz.back() > (size_t)SC_BASE && sz.back() <= tw_resident) {
+      top_lookback = true;
+      break;
+    }
+  }
   size_t tot_entries = 0;
   for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
   if (sz.size() == 1) tot_entries = (m + SC_K - 1) / SC_K;       // a small input still goes totals -> base -> replay
+  const u32 top_tiles = top_lookback ? (u32)((sz.back() + SC_TILE - 1) / SC_TILE) : 0u;
+  const size_t lvl_bytes = (tot_entries * 48 + 64 + 255) / 256 * 256, ctl_bytes = top_lookback ? 64 + (size_t)top_tiles * 48 : 0;
   OrderScope order_scope(ctx, ctx->ord_poly, st);
   int rc = order_scope.rc;
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, tot_entries * 48 + 64);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, lvl_bytes + ctl_bytes);
   if (rc) return rc;
   if (sz.size() == 1) sz.push_back((m + SC_K - 1) / SC_K);
   std::vector<u32x4*> lvl(sz.size());
@@ -1043,7 +1071,21 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
       hipLaunchKernelGGL(ruf_totals_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)lvl[i], sz[i], lvl[i + 1],
                          sz[i + 1], zl[i]);
   }
-  hipLaunchKernelGGL(ruf_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last], zl[last]);
+  if (top_lookback) {
+    u32* ctl = (u32*)((char*)ctx->poly_ws.ptr + lvl_bytes);
+    HFr zlast = zz;
+    for (size_t i = 0; i < last; ++i) zlast = hfr_pow_u64(zlast, SC_K);        // this level's multiplier z^(SC_K^last)
+    RufLook lk2;
+    const HFr zt = hfr_pow_u64(zlast, SC_TILE);
+    to_limbs29(lk2.z, zlast);
+    to_limbs29(lk2.zt, zt);
+    to_limbs29(lk2.zt64, hfr_pow_u64(zt, 64));
+    PM_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, st));
+    hipLaunchKernelGGL(ruf_lookback_kernel<true>, dim3(top_tiles), dim3(256), 0, st, (const u32x4*)lvl[last], sz[last], sz[last],
+                       lvl[last], ctl, top_tiles, lk2);
+  } else {
+    hipLaunchKernelGGL(ruf_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last], zl[last]);
+  }
   for (size_t i = last; i-- > 0;) {     // carries of level i + 1 -> outputs of level i
     const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
     if (i == 0)

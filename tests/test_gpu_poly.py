@@ -40,7 +40,8 @@ def test_evaluate(ctx, oracle, n):
     assert np.array_equal(_poly(ctx, c).evaluate(one), oracle.fr_poly_evaluate(c, one))      # p(1) = sum c_i
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 256, 257, 258, 2048, 2049, 2050, 4097, 5000, (1 << 16) + 1, (1 << 20) + 5, (1 << 21) + 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 256, 257, 258, 2048, 2049, 2050, 4097, 5000, (1 << 16) + 1, (1 << 20) + 5, (1 << 21) + 3,
+                               (1 << 22) + 1, (1 << 22) + 77, (1 << 23) + 5])
 def test_ruffini(ctx, oracle, n):
     c = oracle.fr_sample(7 + n, n)
     try:
