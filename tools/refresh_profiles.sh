@@ -15,7 +15,7 @@ cp $O/small_proofs.txt profiles/${R}_small_proofs.txt
 cp $O/proof_latency_trace.txt profiles/${R}_proof_latency_trace.txt
 cp $O/pytest_gpu.txt profiles/${R}_pytest_gpu.txt
 cp $O/sort_bench.txt profiles/${R}_sort_bench.txt
-cp $O/poly_rows.txt profiles/${R}_poly_rows.txt
+cp $O/poly_rows.txt profiles/${R}_poly_rows_2p22.txt
 cp $O/prover20.txt profiles/${R}_prover_2p20.txt
 python3 - <<PY
 import json
