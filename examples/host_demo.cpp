@@ -141,7 +141,11 @@ int main() {
                  return 0;
                }, nullptr, nullptr};
     DistProverKey dpk(ctx, d1, sel, sigma, gn, ck64);
+    ctx.comm_stats(true);
     REQUIRE(dpk.prove(ck64, dwit).bytes == proof.bytes && dpk.verifier_key() == pk.verifier_key() && dpk.device_bytes() > 0);
+    // what the same proof would put on the wire with more than one rank: 12 transposes = all-to-all calls, 8 message all-gathers
+    const Context::CommStats cs = ctx.comm_stats();
+    REQUIRE(cs.transpose_steps == 12 && cs.allgather_calls == 8 && cs.alltoall_calls == 0);
     std::printf("host_demo OK (EvaluationDomain, msm_variable_base, CommitKey, Polynomial, ProverKey, DistProverKey over %s)\n", pm_version());
     return 0;
   } catch (const Error& e) {

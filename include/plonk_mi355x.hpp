@@ -52,6 +52,13 @@ class Context {
   void sync() const { check(pm_sync(h_)); }
   // release cached workspaces / twiddle tables (regrown on demand); returns the bytes given back
   size_t trim() const { size_t f = 0; check(pm_trim(h_, &f)); return f; }
+  // exchange counters since the last reset (pm_comm_stats): what a multi-GPU deployment pays per proof, countable on one GPU
+  struct CommStats { uint64_t alltoall_calls, alltoall_bytes, allgather_calls, transpose_steps; };
+  CommStats comm_stats(bool reset = false) const {
+    uint64_t v[4];
+    check(pm_comm_stats(h_, v, reset ? 1 : 0));
+    return CommStats{v[0], v[1], v[2], v[3]};
+  }
 
  private:
   pm_ctx* h_ = nullptr;

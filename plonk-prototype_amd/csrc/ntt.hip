@@ -948,18 +948,29 @@ extern "C" int pm_fr_ntt_fourstep_batch_dev(pm_ctx* ctx, void* d_inout, uint32_t
     rc = transpose(x, na / world, nb, pre, none, false, false, &cur);
     if (rc) return rc;
   }
-  // 2: B/W transforms of size A over the columns, every vector of the batch (the blocks are contiguous: one call)
-  rc = pm_fr_ntt_dev(ctx, cur, na, na, x, na, la, batch * (nb / world), sub, nullptr);
+  // `count` contiguous transforms of 2^lg points, in -> out (the batched passes put the batch on gridDim.y: at most 65535 per launch)
+  auto sub_ntts = [&](const void* in, void* out, uint32_t lg, size_t count) -> int {
+    const size_t len = (size_t)1 << lg;
+    for (size_t done = 0; done < count;) {
+      const uint32_t now = (uint32_t)std::min<size_t>(count - done, 32768);
+      int r = pm_fr_ntt_dev(ctx, (const char*)in + done * len * 32, len, len, (char*)out + done * len * 32, len, lg, now, sub, nullptr);
+      if (r) return r;
+      done += now;
+    }
+    return PM_OK;
+  };
+  // 2: B/W transforms of size A over the columns, every vector of the batch (the blocks are contiguous)
+  rc = sub_ntts(cur, x, la, (size_t)batch * (nb / world));
   if (rc) return rc;
   // 3: [B/W][A] -> [A/W][B], element (j, k1) times w^(j k1) on the way out; with a halo one more row: the next rank's first
   const FsMul tw{1, (const u32x4*)dt->tw_hi, (const u32x4*)dt->tw_lo, dt->lh, rank * (nb / world)};
   rc = transpose(x, nb / world, na, tw, none, false, want_halo, &cur);
   if (rc) return rc;
   // 4: A/W transforms of size B over the rows (and over the halo rows: one per vector, contiguous in d_halo)
-  rc = pm_fr_ntt_dev(ctx, cur, nb, nb, x, nb, lb, batch * (na / world), sub, nullptr);
+  rc = sub_ntts(cur, x, lb, (size_t)batch * (na / world));
   if (rc) return rc;
   if (want_halo) {
-    rc = pm_fr_ntt_dev(ctx, d_halo, nb, nb, d_halo, nb, lb, batch, sub, nullptr);
+    rc = sub_ntts(d_halo, d_halo, lb, batch);
     if (rc) return rc;
   }
   if (transposed && !inverse) return PM_OK;

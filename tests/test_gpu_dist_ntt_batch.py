@@ -67,6 +67,22 @@ def test_batched_four_step(ctx, oracle, world, log_n, batch):
             assert np.array_equal(out[("back", cos)], mine), (r, cos, "inverse of the transposed order")
 
 
+def test_batched_four_step_with_more_sub_transforms_than_a_grid_dimension(ctx, oracle):
+    """1100 vectors of 2^12 points on one rank: 70400 sub-transforms of 64 points per step -- more than the 65535 a launch takes
+    on its batch dimension (a 2^24-gate distributed proof on ONE rank has 20 x 4096 of them): the library splits the step."""
+    import torch
+    log_n, batch = 12, 1100
+    n = 1 << log_n
+    x = oracle.fr_sample(77, n * batch)
+    d = torch.from_numpy(x.view(np.int64).copy()).cuda()
+    stage = torch.empty((batch * n, 4), dtype=torch.int64, device="cuda")
+    ctx.fr_ntt_fourstep_batch_dev(d.data_ptr(), batch, stage.data_ptr(), log_n, 1, 0, 2, None)
+    ctx.sync()
+    got = d.cpu().numpy().view(np.uint64)
+    for v in (0, 1, 511, 512, 1023, 1099):
+        assert np.array_equal(got[v * n:(v + 1) * n], ctx.fr_ntt(x[v * n:(v + 1) * n], log_n, 2)), v
+
+
 def test_batched_four_step_rejects_bad_arguments(ctx):
     import torch
     import plonk_prototype_amd as pa
