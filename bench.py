@@ -354,8 +354,9 @@ def main():
                                f"pair around every kernel); `value` is from the loop with the timers off",
                 "pmc_evidence": "profiles/r0N_pmc_summary.json (offline rocprofv3 --pmc passes of this command, tools/collect_pmc.sh)",
                 "note": "integer-ALU bound (Fr products: DESIGN.md section 2 for the issue ceiling by opcode class).  A 2^20 pass is ONE "
-                        "round of 256 one-per-CU workgroups: its load (~8 us) and store (~9 us) do not overlap the arithmetic, so about "
-                        "a third of the launch is not arithmetic and an issue-ceiling fraction quoted for the pass is not a "
+                        "round of workgroups (r05: 512 of two columns, two per CU; r01 - r04: 256 of four columns, one per CU): load, "
+                        "barrier-separated exchange steps and store of a workgroup overlap only with its one neighbour's, so about a "
+                        "quarter of the launch is not arithmetic and an issue-ceiling fraction quoted for the pass is not a "
                         "whole-kernel efficiency"}
 
     # ------------------------------------------------------------------ the one JSON line, and a safety net for N > 1

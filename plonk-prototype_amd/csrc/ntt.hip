@@ -75,7 +75,10 @@ static Plan make_plan(unsigned log_n, int tile_log, int max_radix = 10, int radi
     // tile_log 0 = auto (measured, profiles/r01_ntt_sweep.txt): 2^10-element tiles for S <= 8 (four
     // or more independent workgroups per CU, so barrier phases of one overlap arithmetic of
     // another), never fewer than 4 adjacent columns (64-byte runs per limb group)
-    int lt = tile_log ? tile_log - p.S[i] : std::max(10 - p.S[i], 2);
+    // r05: a radix-2^10 pass takes TWO columns per workgroup (512 threads, 73 KB of LDS: two workgroups per CU whose load / barrier /
+    // store phases overlap) -- with the r05 product (95 - 106 VGPRs) that is 204 -> 195 us per forward + inverse 2^20 transform and
+    // 206 -> 191 us in a batch of four (profiles/r05_ntt_tile_ab.txt; r02 measured no difference with the 128-VGPR kernels)
+    int lt = tile_log ? tile_log - p.S[i] : (p.S[i] >= 10 && radix == 4 ? 1 : std::max(10 - p.S[i], 2));
     if (p.S[i] < 8 && lt > 11 - p.S[i]) lt = 11 - p.S[i];  // 2^12-element tiles exist for S >= 8 only
     if (!tile_log && radix == 4) {
       // fill the chip: narrower tiles while there are fewer tiles than CUs (measured, profiles/r02_ntt_tile_ab.txt:

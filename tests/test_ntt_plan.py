@@ -48,7 +48,8 @@ def test_default_plan_for_every_domain_size(lib):
             _check(p, log_n, (log_n, batch, p))
     assert _plan(lib, 32)[0] == -2 and _plan(lib, 40)[0] == -2       # PM_ERR_DOMAIN_TOO_LARGE, as EvaluationDomain::new
     rc, p = _plan(lib, 20)
-    assert p["S"] == [10, 10] and p["LT"] == [2, 2] and p["threads"] == [1024, 1024]   # BASELINE configs[1]: one tile per CU
+    # BASELINE configs[1]: two radix-2^10 passes, two columns per workgroup = two 512-thread workgroups per CU (r05; r01 - r04: four columns, one)
+    assert p["S"] == [10, 10] and p["LT"] == [1, 1] and p["threads"] == [512, 512]
     assert _plan(lib, 24)[1]["S"] == [8, 8, 8] and _plan(lib, 30)[1]["S"] == [10, 10, 10]
     # fewer tiles than CUs: narrower tiles (2^18: 2^9 x 2^9 with two columns)
     p18 = _plan(lib, 18)[1]
