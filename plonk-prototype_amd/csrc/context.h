@@ -60,7 +60,8 @@ struct pm_ctx {
   pm::DeviceBuffer ntt_tmp[2];
   pm::DeviceBuffer io_in, io_out;                       // staging for host-pointer calls
   pm::StreamOrder ord_ntt, ord_msm, ord_poly;           // cross-stream ordering of the shared scratch + tables
-  // host timeline (diagnostic, PM_HOST_MARKS=1 in the environment): (label, microseconds) pairs, printed by the prover
+  // host timeline (diagnostic, PM_HOST_MARKS=1 in the environment): (label, microseconds) pairs, printed by the prover.  Not
+  // synchronised: meant for one proving thread per context (several threads in one context would interleave their marks)
   bool marks_on = false;
   std::vector<std::pair<const char*, double>> marks;
   unsigned long long stat_alltoall_calls = 0, stat_alltoall_bytes = 0, stat_allgather_calls = 0, stat_transpose_steps = 0;   // pm_comm_stats
