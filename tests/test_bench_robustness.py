@@ -7,7 +7,12 @@ the pieces that protect the first multi-GPU run -- no GPU, two `gloo` ranks.
 * a rank that cannot create ITS communicator after a good id: the agreement makes every rank drop to the fallback;
 * a stalled phase: the watchdog prints the one line and every rank exits with a NON-ZERO code; armed before the first
   collective (a stall with no headline yet still produces a line and code 3);
-* the line is printed once even when the watchdog and the main thread race.
+* the line is printed once even when the watchdog and the main thread race;
+* a bare `python3 bench.py --gpus N` (no torch.distributed.run, WORLD_SIZE unset: the driver's command shape) is its own
+  launcher (VERDICT r05 "next" item 1): N child ranks with the rendezvous environment, rank 0's line relayed once, the
+  largest child code returned, a silent child ended at the launcher's deadline with a non-zero code and a null line;
+* a rank other than 0 fires its watchdog later than rank 0, and a teardown that hangs after the complete line
+  does not turn the run into a failure.
 """
 import json
 import os
@@ -163,3 +168,105 @@ def test_the_line_is_printed_once_when_watchdog_and_main_thread_race():
     for _ in range(3):
         rc, lines = _run_stall(first=20, second=0.5, headline=True, race=True)
         assert len(lines) == 1 and rc in (0, 3), (rc, lines)
+
+
+# ---------------------------------------------------------------------------------------------- the bare launcher
+_STUB = r"""
+import json, os, signal, sys, time
+mode, piddir = sys.argv[1], sys.argv[2]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+open(os.path.join(piddir, f"pid{rank}"), "w").write(str(os.getpid()))
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert int(os.environ["LOCAL_RANK"]) == rank
+if mode == "silent":
+    time.sleep(120)                       # the rank that never prints
+if rank == 0:
+    print("RCCL banner on stdout", flush=True)
+    print(json.dumps({"metric": "m", "value": 1.0, "world": world, "rank": rank}), flush=True)
+    if mode == "twice":
+        print(json.dumps({"metric": "m", "value": 2.0}), flush=True)
+else:
+    print(json.dumps({"metric": "m", "value": -1.0, "rank": rank}), flush=True)     # not rank 0: must not be relayed
+    if mode == "exit3":
+        sys.exit(3)
+    if mode == "sigkill":
+        os.kill(os.getpid(), signal.SIGKILL)
+"""
+
+
+def _run_launcher(tmp_path, mode, n=2, deadline=30):
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launcher-timeout", str(deadline),
+                        "--child-cmd", f"{sys.executable} {stub} {mode} {tmp_path}"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr
+
+
+def test_bare_gpus_n_starts_its_own_ranks_and_relays_one_line(tmp_path):
+    rc, lines, err = _run_launcher(tmp_path, "twice", n=3)
+    assert rc == 0 and len(lines) == 1, (rc, lines, err)
+    line = json.loads(lines[0])
+    assert line == {"metric": "m", "value": 1.0, "world": 3, "rank": 0}
+    assert "has imported torch: False" in err                     # the launcher makes no GPU call: it never loads torch
+    assert "RCCL banner on stdout" in err and "-1.0" in err       # every other stdout byte of the ranks lands on stderr
+    assert sorted(os.listdir(tmp_path))[:3] == ["pid0", "pid1", "pid2"]
+
+
+def test_launcher_returns_the_largest_child_code(tmp_path):
+    rc, lines, _ = _run_launcher(tmp_path, "exit3")
+    assert rc == 3 and len(lines) == 1 and json.loads(lines[0])["value"] == 1.0
+    rc, lines, _ = _run_launcher(tmp_path, "sigkill")
+    assert rc == 128 + 9 and len(lines) == 1
+
+
+def test_launcher_deadline_ends_silent_ranks_with_a_null_line(tmp_path):
+    rc, lines, err = _run_launcher(tmp_path, "silent", deadline=2)
+    assert rc != 0 and len(lines) == 1, (rc, lines, err)
+    line = json.loads(lines[0])
+    assert line["value"] is None and "deadline" in line["note"]
+    for r in range(2):                                            # the exact PIDs it started are gone
+        pid = int((tmp_path / f"pid{r}").read_text())
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
+
+
+def test_under_a_launcher_the_world_size_must_match():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
+
+
+_GRACE = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import bench
+t0 = time.monotonic()
+fired = []
+dog = bench.Watchdog(0.5, lambda phase: fired.append((phase, time.monotonic() - t0)), "startup",
+                     exit_fn=lambda code: fired.append(code), grace={grace})
+time.sleep(0.1)
+if {teardown}:
+    dog.extend(0.5, "teardown", exit_code=0)
+time.sleep({grace} + 1.5)
+print(repr(fired))
+"""
+
+
+def _run_grace(grace, teardown):
+    p = subprocess.run([sys.executable, "-c", _GRACE.format(root=ROOT, grace=grace, teardown=teardown)],
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    return eval(p.stdout.strip())                                 # noqa: S307 -- our own repr
+
+
+def test_other_ranks_fire_after_rank_zero_and_teardown_hang_exits_zero():
+    r0 = _run_grace(0.0, False)
+    r1 = _run_grace(1.0, False)
+    assert r0[0][0] == "startup" and r0[1] == 3 and r1[1] == 3
+    assert 0.5 <= r0[0][1] < 1.2 and r1[0][1] >= 1.5              # the grace separates them
+    td = _run_grace(0.0, True)
+    assert td[0][0] == "teardown" and td[1] == 0
