@@ -107,6 +107,7 @@ struct pm_ctx {
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_max_pairs = 0;    // 0 = 2^31 - 1; a batched MSM with more (digit, point) pairs runs in halves
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
+  long opt_binv_quads = 0;       // batch inversion: quads (4 elements) per thread and inversion; 0 = auto
   long opt_poly_lookback = 1;    // prefix product in one pass (decoupled look-back) instead of totals / scan / replay
   long opt_msm_pipeline = 0;     // 1: a batched MSM runs as up to four pieces on two streams (measured: loses, see msm.hip)
   int num_cus = 256;
@@ -158,6 +159,7 @@ inline void host_mark(pm_ctx* ctx, const char* label) {
   if (ctx && ctx->marks_on)
     ctx->marks.emplace_back(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
 }
+int fr_batch_inverse_mul(pm_ctx* ctx, void* d_inout, const void* d_mul, size_t n, void* hip_stream);   // poly.hip: mul_i / v_i in place
 int poly_evaluate_groups(pm_ctx* ctx, uint32_t groups, const uint32_t* k, const void* const* const* polys,
                          const uint64_t* const* points, uint64_t* const* outs, size_t n);   // poly.hip
 int coset_expand(pm_ctx* ctx, const void* const* d_src, uint32_t count, const void* d_gs_pow, size_t m, void* d_out);

@@ -68,6 +68,17 @@ PM_DEV Fe<P> fe_inv_int(const Fe<P>& y) {
     v[i] = 0;
   }
   for (int round = 0; round < ROUNDS; ++round) {
+    // ---- a == 0 in every lane of the wave: the remaining rounds only multiply b's row of the matrix by 2^W and divide
+    // it out again (b and v keep their values, v up to a multiple of m), so the wave leaves together.  ROUNDS covers the
+    // worst case (2 bits(m) - 1 steps); random inputs need ~1.41 bits(m) steps (Fr: 13 of the 18 rounds, r06).  The vote
+    // is wave-uniform: no divergence, and the result does not depend on which lanes share the wave (the skipped rounds
+    // change the representative of v, not its class; callers reduce it)
+    {
+      u32 any_a = 0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) any_a |= a[i];
+      if (__all(any_a == 0)) break;
+    }
     // ---- approximations: low W bits | top W + 2 bits of max(a, b) (both numbers cut at the same position)
     u32 a2 = 0, a1 = 0, a0 = 0, b2 = 0, b1 = 0, b0 = 0;
     bool found = false;

@@ -465,283 +465,195 @@ __global__ void __launch_bounds__(256) pp_lookback_kernel(const u32x4* in, size_
   tile_store(out, (long long)tile0, false, (long long)(n - tile0), sc_lds, w);
 }
 
-// ---- Ruffini.  Level 0 reads the coefficients top down: d_k = c_{n-1-k}, k < m = n - 1, and writes
-// out[m-1-k] = y_k; inner levels hold ABI-form 48-byte entries (lazily reduced) and are scanned in place.
-// y = d + z y: ABI + device x ABI stays ABI form, value < 3 r, limbs < 2^30.
-struct RufLevel {
-  u32 z[9];       // this level's multiplier z^(SC_K^level), device form
-};
-// level 0: tile over k in [tile0, tile0 + SC_TILE), element k = coefficient n_coeffs - 1 - k (walked downwards)
-__global__ void __launch_bounds__(256) ruf_totals0_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, u32x4* tot,
-                                                           const RufLevel lv) {
-  extern __shared__ u32x4 sc_lds[];
-  const size_t tile0 = (size_t)blockIdx.x * SC_TILE;
-  u32 w[SC_K][8];
-  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
-  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x, lo = chunk * SC_K;
-  if (lo >= m) return;
-  const Fr z = fr_limbs(lv.z);
-  Fr y = fe_zero<FrP>();
-  // a short last chunk is padded at the END with zeros: y -> z y, so that every chunk spans exactly SC_K steps
-#pragma unroll
-  for (int k = 0; k < SC_K; ++k) {
-    y = fe_mul<FrP>(y, z);
-    if (lo + k < m) y = fe_add<FrP>(y, fe_unpack<FrP>(w[k]));
-  }
-  st_tw(tot, chunk, fe_reduce_weak<FrP>(y));
-}
-// carry[chunk] = y just before the chunk; out[m - 1 - k] = y_k, canonical
-__global__ void __launch_bounds__(256) ruf_replay0_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, const u32x4* carry,
-                                                           u32x4* out, const RufLevel lv) {
-  extern __shared__ u32x4 sc_lds[];
-  const size_t tile0 = (size_t)blockIdx.x * SC_TILE;
-  u32 w[SC_K][8];
-  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
-  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x, lo = chunk * SC_K;
-  if (lo < m) {
-    const Fr z = fr_limbs(lv.z);
-    Fr y = ld_tw(carry, chunk);
-#pragma unroll
-    for (int k = 0; k < SC_K; ++k) {
-      if (lo + k < m) {
-        y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), fe_unpack<FrP>(w[k])));
-        fe_canon_pack<FrP>(w[k], y);
-      }
-    }
-  }
-  tile_store(out, (long long)(m - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
-}
-// inner levels: ABI-form 48-byte entries, scanned in place
-__global__ void __launch_bounds__(256) ruf_totals_kernel(const u32x4* in, size_t m, u32x4* tot, size_t nchunks,
-                                                          const RufLevel lv) {
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= nchunks) return;
-  const Fr z = fr_limbs(lv.z);
-  const size_t lo = t * SC_K;
-  Fr a[SC_K];
-#pragma unroll
-  for (int k = 0; k < SC_K; ++k) a[k] = lo + k < m ? ld_tw(in, lo + k) : fe_zero<FrP>();
-  Fr y = fe_zero<FrP>();
-#pragma unroll
-  for (int k = 0; k < SC_K; ++k) y = fe_add<FrP>(fe_mul<FrP>(y, z), a[k]);
-  st_tw(tot, t, fe_reduce_weak<FrP>(y));
-}
-// carry[t] = y just before chunk t of this level; every entry k is replaced by the carry INTO it (y_{k-1}): that is
-// what the level below replays from
-__global__ void __launch_bounds__(256) ruf_replay_kernel(u32x4* v, size_t m, const u32x4* carry, size_t nchunks,
-                                                          const RufLevel lv) {
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= nchunks) return;
-  const Fr z = fr_limbs(lv.z);
-  const size_t lo = t * SC_K;
-  Fr a[SC_K];
-#pragma unroll
-  for (int k = 0; k < SC_K; ++k) a[k] = lo + k < m ? ld_tw(v, lo + k) : fe_zero<FrP>();
-  Fr y = ld_tw(carry, t);
-#pragma unroll
-  for (int k = 0; k < SC_K; ++k) {
-    if (lo + k < m) st_tw(v, lo + k, y);
-    y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), a[k]));
-  }
-}
-// one workgroup, m <= SC_BASE entries T_k (ABI form): in place T_k <- y_{k-1} (the carry INTO chunk k), where
-// y_k = T_k + z y_{k-1}, y_{-1} = 0.
-__global__ void __launch_bounds__(256) ruf_base_kernel(u32x4* v, u32 m, const RufLevel lv) {
-  __shared__ u32 sh[4 * 9];
-  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const Fr z = fr_limbs(lv.z);
-  const u32 lo = t * SC_K;
-  Fr y = fe_zero<FrP>();
-  for (u32 k = lo; k < lo + SC_K; ++k) {     // padded like the totals: every thread spans SC_K steps
-    y = fe_mul<FrP>(y, z);
-    if (k < m) y = fe_add<FrP>(y, ld_tw(v, k));
-  }
-  y = fe_reduce_weak<FrP>(y);
-  // inclusive scan over the threads: Y_t = y_t + z^(SC_K) Y_{t-1}; the multiplier of a step of d threads is z^(SC_K d)
-  Fr zp = z;
-  for (int i = 1; i < SC_K; i <<= 1) zp = fe_mul<FrP>(zp, zp);   // z^SC_K (SC_K is a power of two)
-  Fr incl = y;
-  for (int d = 1; d < 64; d <<= 1) {
-    const Fr o = fr_shfl_up(incl, d);
-    if (lane >= (u32)d) incl = fe_reduce_weak<FrP>(fe_add<FrP>(incl, fe_mul<FrP>(o, zp)));
-    zp = fe_mul<FrP>(zp, zp);
-  }
-  // zp = z^(SC_K 64): one wave's span
-  if (lane == 63) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = incl.l[i];
-  }
-  Fr carry = fr_shfl_up(incl, 1);            // y before this thread, inside the wave
-  if (lane == 0) carry = fe_zero<FrP>();
-  __syncthreads();
-  // what enters this wave: W = sum over earlier waves; then it reaches lane l multiplied by z^(SC_K l)
-  Fr wcar = fe_zero<FrP>();
-  for (u32 w = 0; w < wave; ++w) {
-    Fr o;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o.l[i] = sh[w * 9 + i];
-    wcar = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(wcar, zp), o));
-  }
-  if (wave > 0) {
-    Fr zl = fe_one<FrP>(), b = z;              // z^(SC_K lane) by square-and-multiply on (SC_K lane)
-    for (u32 e = SC_K * lane; e; e >>= 1) {
-      if (e & 1) zl = fe_mul<FrP>(zl, b);
-      b = fe_mul<FrP>(b, b);
-    }
-    carry = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(wcar, zl)));
-  }
-  y = carry;
-  for (u32 k = lo; k < lo + SC_K && k < m; ++k) {
-    const Fr a = ld_tw(v, k);
-    st_tw(v, k, y);
-    y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), a));
-  }
-}
-// Ruffini in ONE pass (r03): the same decoupled look-back as pp_lookback_kernel, for y_k = d_k + z y_{k-1}.  A tile's
-// published value is the y at its end computed from a zero start (status 1) or from the true carry (status 2); a value
-// `b` tiles back enters this tile multiplied by (z^SC_TILE)^(b-1), so every lane of the walking wave keeps its own
-// power of z^SC_TILE (one product per round) next to its running sum.  Forms as in the kernels above: values ABI,
-// multipliers device.
-struct RufLook {
+// ---- Ruffini: d_k = c_{n-1-k}, k < m = n - 1 (the coefficients read top down), y_k = d_k + z y_{k-1}, out[m-1-k] = y_k.
+// y = d + z y: ABI + device x ABI stays ABI form.
+// ---- Ruffini as a SCALED PREFIX SUM (r06).  y_k = d_k + z y_{k-1} has a constant multiplier, so the scan over the threads
+// needs no products: with c_g the value thread g's chunk of SC_K elements reaches from a zero start, the true value at the
+// end of chunk g is  Y_g = sum_{h <= g} c_h z^(K (g - h)) = z^(K g) S_g,  S_g = sum_{h <= g} v_h,  v_h = c_h z^(-K h):
+// a plain prefix SUM of the scaled chunk values.  Per thread: K products for c_g, two for v_g (the power from a two-level
+// table: z^(-TILE tile) x z^(-K t)), ADDITIONS for the wave scan, the tile total and the decoupled look-back over the
+// tiles, two products for the carry Y_{g-1} = z^(K (g - 1)) S_{g-1}, K products to replay: 2 K + 4 = 20 products per 8
+// elements (2.5 per element), none of them on a chain longer than the thread's own -- against ~4.5 per element and 6 x 3
+// dependent products in the wave scan plus a product per look-back round in ruf_lookback_kernel (r03 - r05), whose
+// latency made 2^20 (the prover's size) cost 79 us.  Three stages (chunk values and in-tile sums | the tile sums scanned by
+// one workgroup | carries and replay): a decoupled look-back over the tiles -- tried first, additions only -- still spends
+// its time waiting on the in-flight predecessors' records (2^22: 245 us against 177 for the r05 hybrid).
+// Forms as above: values ABI, multipliers device.  Tables at `tab` (48-byte device-form entries):
+//   neg_lo[256]: z^(-K t) | pos_lo[256]: z^(K (t - 1)) | neg_hi[tiles]: z^(-TILE T) | pos_hi[tiles]: z^(TILE T)
+struct RufSum {
   u32 z[9];        // z
-  u32 zt[9];       // z^SC_TILE
-  u32 zt64[9];     // z^(64 SC_TILE)
+  u32 one[9];
 };
-// TW (r05): the vector is an INNER level of the chunked scan -- ABI-form 48-byte entries T_k in forward order, multiplier z = this
-// level's z^(SC_K^level) -- scanned in place: T_k <- y_{k-1}, the carry INTO chunk k (what ruf_base_kernel leaves).
-template <bool TW>
-__global__ void __launch_bounds__(256) ruf_lookback_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, u32x4* out,
-                                                            u32* ctl, u32 tiles, const RufLook lk) {
+// base^(2^j), j < RUF_POW_BITS, of the four table bases (host side: 4 x 13 squarings), so that a table entry is the
+// product of the powers its index has bits for -- at most 13 dependent products, ~6 on average, instead of the 26 of a
+// square-and-multiply from the base (the table kernel is a latency chain in front of stage 1: 16 us -> 5 at 2^20)
+constexpr int RUF_POW_BITS = 14;     // 2^14 tiles x 2048 = 2^25 elements per table; larger vectors fall back to fr_pow
+struct RufPowers {
+  u32 p[4][RUF_POW_BITS][9];   // [neg_lo | pos_lo | neg_hi | pos_hi]: z^-K, z^K, z^-TILE, z^TILE
+  u32 pos_lo_scale[9];         // z^-K: pos_lo[t] = z^(K (t - 1))
+};
+__global__ void __launch_bounds__(256) ruf_sum_tables_kernel(u32x4* tab, const RufPowers c, const RufSum k, u32 tiles) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 512 + 2 * tiles) return;
+  const u32 which = i < 256 ? 0u : i < 512 ? 1u : i < 512 + tiles ? 2u : 3u;
+  u32 e = which == 0 ? i : which == 1 ? i - 256 : which == 2 ? i - 512 : i - 512 - tiles;
+  Fr acc = which == 1 ? fr_limbs(c.pos_lo_scale) : fr_limbs(k.one);
+  if (e >> RUF_POW_BITS) {   // beyond the precomputed squarings: finish from the top power
+    acc = fr_pow(fr_limbs(c.p[which][RUF_POW_BITS - 1]), (unsigned long long)(e >> RUF_POW_BITS) << 1, acc);
+    e &= (1u << RUF_POW_BITS) - 1u;
+  }
+#pragma unroll 1
+  for (int j = 0; j < RUF_POW_BITS; ++j)
+    if ((e >> j) & 1u) acc = fe_mul<FrP>(acc, fr_limbs(c.p[which][j]));
+  st_tw(tab, i, fr_canon(acc));
+}
+PM_DEV Fr fr_wadd(const Fr& a, const Fr& b) { return fe_reduce_weak<FrP>(fe_add<FrP>(a, b)); }
+// stage 1: per thread the scaled chunk value v_g; its exclusive sum over the earlier threads of the tile -> pre[g], the
+// tile's sum -> tot[tile] (48-byte ABI-form entries)
+__global__ void __launch_bounds__(256) ruf_sum_totals_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, u32x4* pre, u32x4* tot,
+                                                              const RufSum lk, const u32x4* tab) {
   extern __shared__ u32x4 sc_lds[];
-  __shared__ u32 sh[4 * 9 + 9 + 9];
-  __shared__ u32 s_tile;
-  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  u32* rec = ctl + 16;                    // 12 words per tile
-  if (t == 0) s_tile = atomicAdd(ctl, 1u);
-  __syncthreads();
-  const u32 tile = s_tile;
-  if (tile >= tiles) return;
+  __shared__ u32 sh[4 * 9];
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6, tile = blockIdx.x;
+  const u32x4 *neg_lo = tab, *neg_hi = tab + 3 * 512;
   const size_t tile0 = (size_t)tile * SC_TILE;
   u32 w[SC_K][8];
-  if (!TW) tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);
+  const Fr nlo = ld_tw(neg_lo, t), nhi = ld_tw(neg_hi, tile);   // requested before the recurrence, used after it
   const size_t lo = tile0 + (size_t)t * SC_K;
-  const Fr z = fr_limbs(lk.z), one = fe_one<FrP>(), zero = fe_zero<FrP>();
-  // 1 the thread's chunk from a zero start (a short last chunk is padded at the end with zeros: y -> z y)
-  Fr d[SC_K];
+  const Fr z = fr_limbs(lk.z), zero = fe_zero<FrP>();
+  // the thread's chunk from a zero start (a short last chunk is padded at the end with zeros: y -> z y; nothing follows it)
   Fr y = zero;
-  if (TW) {
-#pragma unroll
-    for (int k = 0; k < SC_K; ++k) d[k] = lo + k < m ? ld_tw(coeffs, lo + k) : zero;   // all loads in flight at once
-  }
 #pragma unroll
   for (int k = 0; k < SC_K; ++k) {
-    if (!TW) d[k] = lo + k < m ? fe_unpack<FrP>(w[k]) : zero;
-    y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
+    const Fr d = lo + k < m ? fe_unpack<FrP>(w[k]) : zero;
+    y = k == 0 ? d : fr_wadd(fe_mul<FrP>(y, z), d);
   }
-  // 2 inclusive scan over the threads of the wave: Y_t = y_t + z^SC_K Y_{t-1}; beside it the powers z^(SC_K (lane + 1))
-  Fr zp = z;
-  for (int i = 1; i < SC_K; i <<= 1) zp = fe_mul<FrP>(zp, zp);   // z^SC_K
-  Fr inc = y, pw = zp;
+  Fr inc = fe_mul<FrP>(y, fe_mul<FrP>(nhi, nlo));                // v_g = c_g z^(-K g)
   for (int dd = 1; dd < 64; dd <<= 1) {
-    const Fr o = fr_shfl_up(inc, dd), po = fr_shfl_up(pw, dd);
-    if (lane >= (u32)dd) {
-      inc = fe_reduce_weak<FrP>(fe_add<FrP>(inc, fe_mul<FrP>(o, zp)));
-      pw = fe_mul<FrP>(pw, po);
-    }
-    zp = fe_mul<FrP>(zp, zp);
+    const Fr o = fr_shfl_up(inc, dd);
+    if (lane >= (u32)dd) inc = fr_wadd(inc, o);
   }
-  // zp = z^(SC_K 64): one wave's span; pw = z^(SC_K (lane + 1))
   if (lane == 63) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = inc.l[i];
   }
-  Fr carry = fr_shfl_up(inc, 1), mult = fr_shfl_up(pw, 1);   // y before this thread inside the wave; z^(SC_K lane)
-  if (lane == 0) {
-    carry = zero;
-    mult = one;
-  }
+  Fr excl = fr_shfl_up(inc, 1);          // sum over the earlier threads of this wave
+  if (lane == 0) excl = zero;
   __syncthreads();
-  // what enters this wave from the earlier waves of the tile (zero start), and the tile's total; the thread's
-  // multiplier for whatever enters the TILE: z^(SC_K (64 wave + lane))
-  Fr wcar = zero, tile_total = zero;
+  Fr tile_total = zero;
 #pragma unroll
   for (u32 wv = 0; wv < 4; ++wv) {
     Fr o;
 #pragma unroll
     for (int i = 0; i < 9; ++i) o.l[i] = sh[wv * 9 + i];
-    if (wv < wave) {
-      wcar = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(wcar, zp), o));
-      mult = fe_mul<FrP>(mult, zp);
-    }
-    tile_total = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(tile_total, zp), o));
+    if (wv < wave) excl = fr_wadd(excl, o);
+    tile_total = wv == 0 ? o : fr_wadd(tile_total, o);
   }
-  if (wave > 0) carry = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(wcar, fr_shfl_up(pw, 1))));
-  // (lane 0 of a later wave: fr_shfl_up leaves its own pw, but its in-wave multiplier is one: fix below)
-  if (wave > 0 && lane == 0) carry = wcar;
-  // 3 publish, look back (wave 0), publish the inclusive value
-  if (wave == 0) {
-    Fr C = zero;
-    if (tile > 0) {
-      if (lane == 0) pp_publish(rec + 12 * (size_t)tile, tile_total, 1u);
-      // this lane's power: (z^SC_TILE)^(back - 1 + lane)
-      const Fr zt = fr_limbs(lk.zt), zt64 = fr_limbs(lk.zt64);
-      Fr lp = zt;
-      for (int dd = 1; dd < 64; dd <<= 1) {
-        const Fr po = fr_shfl_up(lp, dd);
-        if (lane >= (u32)dd) lp = fe_mul<FrP>(lp, po);
-      }
-      lp = fr_shfl_up(lp, 1);                      // zt^lane
-      if (lane == 0) lp = one;
-      Fr mine = zero;
-      for (u32 back = 1;; back += 64) {
-        const bool valid = tile >= back + lane;
-        const u32 pred = valid ? tile - back - lane : 0u;
-        u32 stt = valid ? 0u : 2u;                  // beyond tile 0: "inclusive value = zero"
-        Fr got = zero;
-        while (valid && stt == 0u) {
-          stt = pp_fetch(rec + 12 * (size_t)pred, got);
-          if (stt == 0u) __builtin_amdgcn_s_sleep(1);
-        }
-        const u64 done = __ballot(stt == 2u);
-        const u32 first = (u32)__ffsll((long long)done) - 1u;
-        if (valid && (done == 0 || lane <= first)) mine = fe_reduce_weak<FrP>(fe_add<FrP>(mine, fe_mul<FrP>(got, lp)));
-        if (done != 0) break;
-        lp = fe_mul<FrP>(lp, zt64);
-      }
+  st_tw(pre, (size_t)tile * 256 + t, excl);
+  if (t == 0) st_tw(tot, tile, tile_total);
+}
+// stage 2: tot[T] <- sum of tot[0 .. T) (one workgroup; additions only; 2048 entries per sweep, a thread's eight loads in
+// flight together)
+__global__ void __launch_bounds__(256) ruf_sum_carry_kernel(u32x4* tot, u32 tiles) {
+  __shared__ u32 sh[5 * 9];
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const Fr zero = fe_zero<FrP>();
+  Fr carry = zero;                                     // sum of the sweeps before this one
+  for (u32 base = 0; base < tiles; base += 2048) {
+    const u32 lo = base + t * 8;
+    Fr a[8];
 #pragma unroll
-      for (int dd = 32; dd > 0; dd >>= 1) {
-        Fr o;
+    for (int k = 0; k < 8; ++k) a[k] = lo + k < tiles ? ld_tw(tot, lo + k) : zero;
+    Fr sum = a[0];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) o.l[i] = __shfl_xor(mine.l[i], dd);
-        mine = fe_reduce_weak<FrP>(fe_add<FrP>(mine, o));
-      }
-      C = mine;
+    for (int k = 1; k < 8; ++k) sum = fr_wadd(sum, a[k]);
+    Fr inc = sum;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const Fr o = fr_shfl_up(inc, dd);
+      if (lane >= (u32)dd) inc = fr_wadd(inc, o);
     }
-    if (lane == 0) {
-      const Fr zt = fr_limbs(lk.zt);
-      pp_publish(rec + 12 * (size_t)tile, fe_reduce_weak<FrP>(fe_add<FrP>(tile_total, fe_mul<FrP>(C, zt))), 2u);
+    if (base) __syncthreads();                         // the previous sweep's reads of sh are done
+    if (lane == 63) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) sh[36 + i] = C.l[i];
+      for (int i = 0; i < 9; ++i) sh[wave * 9 + i] = inc.l[i];
+    }
+    Fr run = fr_shfl_up(inc, 1);
+    if (lane == 0) run = zero;
+    run = fr_wadd(run, carry);
+    __syncthreads();
+    Fr all = zero;
+#pragma unroll
+    for (u32 wv = 0; wv < 4; ++wv) {
+      Fr o;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o.l[i] = sh[wv * 9 + i];
+      if (wv < wave) run = fr_wadd(run, o);
+      all = fr_wadd(all, o);
+    }
+    carry = fr_wadd(carry, all);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (lo + k < tiles) st_tw(tot, lo + k, run);
+      run = fr_wadd(run, a[k]);
     }
   }
-  __syncthreads();
-  // 4 replay from y before the thread's chunk = (zero-start carry) + z^(SC_K thread) C
-  Fr C;
+}
+// stage 3: the carry into the thread's chunk, Y_{g-1} = z^(K (g - 1)) S_{g-1}, S_{g-1} = (sum of the tiles before) + pre[g],
+// and the replay.  SUM_TILES: stage 2 did not run (at most 512 tiles -- up to 2^20 elements: a launch costs more than the
+// sums) -- the workgroup adds up tot[0 .. tile) itself, loads in flight together, one reduction.
+template <bool SUM_TILES>
+__global__ void __launch_bounds__(256) ruf_sum_replay_kernel(const u32x4* coeffs, size_t n_coeffs, size_t m, const u32x4* pre,
+                                                              const u32x4* tot, u32x4* out, const RufSum lk, const u32x4* tab, u32 tiles) {
+  extern __shared__ u32x4 sc_lds[];
+  __shared__ u32 sh[4 * 9];
+  const u32 t = threadIdx.x, tile = blockIdx.x;
+  const u32x4 *pos_lo = tab + 3 * 256, *pos_hi = tab + 3 * (512 + (size_t)tiles);
+  const size_t tile0 = (size_t)tile * SC_TILE;
+  const Fr zero = fe_zero<FrP>();
+  Fr before;
+  if (SUM_TILES) {
+    Fr a[8];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) C.l[i] = sh[36 + i];
-  y = fe_reduce_weak<FrP>(fe_add<FrP>(carry, fe_mul<FrP>(C, mult)));
-  if (TW) {
+    for (int k = 0; k < 8; ++k) a[k] = (u32)k * 256 + t < tile ? ld_tw(tot, (size_t)k * 256 + t) : zero;
+    Fr sum = a[0];
 #pragma unroll
-    for (int k = 0; k < SC_K; ++k) {
-      if (lo + k < m) st_tw(out, lo + k, y);
-      y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
+    for (int k = 1; k < 8; ++k) sum = fr_wadd(sum, a[k]);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) {
+      Fr o;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o.l[i] = __shfl_xor(sum.l[i], dd);
+      sum = fr_wadd(sum, o);
     }
-    return;
+    if ((t & 63u) == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sh[(t >> 6) * 9 + i] = sum.l[i];
+    }
+  } else {
+    before = ld_tw(tot, tile);
   }
+  const Fr mine = ld_tw(pre, (size_t)tile * 256 + t);
+  const Fr pw = fe_mul<FrP>(ld_tw(pos_hi, tile), ld_tw(pos_lo, t));
+  u32 w[SC_K][8];
+  tile_load(coeffs, (long long)(n_coeffs - 1 - tile0), true, (long long)(m - tile0), sc_lds, w);   // (its barriers publish sh)
+  if (SUM_TILES) {
+    before = zero;
+#pragma unroll
+    for (u32 wv = 0; wv < 4; ++wv) {
+      Fr o;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o.l[i] = sh[wv * 9 + i];
+      before = wv == 0 ? o : fr_wadd(before, o);
+    }
+  }
+  const size_t lo = tile0 + (size_t)t * SC_K;
+  const Fr z = fr_limbs(lk.z);
+  Fr y = fe_mul<FrP>(fr_wadd(before, mine), pw);
 #pragma unroll
   for (int k = 0; k < SC_K; ++k) {
     if (lo + k < m) {
-      y = fe_reduce_weak<FrP>(fe_add<FrP>(fe_mul<FrP>(y, z), d[k]));
+      y = fr_wadd(fe_mul<FrP>(y, z), fe_unpack<FrP>(w[k]));
       fe_canon_pack<FrP>(w[k], y);
     }
   }
@@ -757,40 +669,81 @@ __global__ void ruffini_shift_kernel(const u32x4* coeffs, u32x4* out, size_t m) 
 }
 
 // ------------------------------------------------------------------ batch inversion
-// Montgomery's trick per thread over `L` elements taken with stride T (coalesced), one inversion per thread.  Forms: u = a * 2^5 (ABI -> device form, a shift and a weak reduction, no
-// product); prefix products in device form; the inverse of the thread's product is moved to ABI form
-// once, after which inverse(ABI) x prefix(device) and inverse(ABI) x u(device) both stay in ABI form:
-// 3 products per element (r01: 6) + one binary-GCD inversion per thread (r03; r02: x^(r-2), ~325 dependent products,
-// a 0.15 ms latency floor however the elements were distributed).
-__global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, size_t n, u32 L, u32x4* scratch) {
+// Montgomery's trick per thread, blocked by QUADS (r06): thread t owns the elements t + k T (k < 4 Q; consecutive lanes,
+// consecutive elements: coalesced) as Q quads {4 j .. 4 j + 3}.  Forward, per quad: the product E_j of its (non-zero)
+// elements -- 3 products, a two-level tree -- and ONE 48-byte scratch entry, the running product before the quad.  One
+// inversion per thread.  Backward, per quad: the elements are read again, 1 / E_j = inv x scratch_j, the four inverses
+// come out of the quad's own two-level tree (7 products), inv moves on by E_j (2 products): 15 products per quad
+// = 3.75 per element and 32 + 12 + 32 + 12 + 32 = 120 bytes per element.  (r01 - r05: one scratch entry per ELEMENT,
+// 3 products and 192 bytes per element -- a streaming kernel at 3.1 TB/s that could not go faster.)
+// Forms: u = a 2^5 (ABI -> device form, a shift and a weak reduction, no product); products in device form; the inverse
+// of the thread's product is moved to ABI form once, after which inverse(ABI) x anything(device) stays in ABI form.
+// The inversion is the binary GCD of field_inv.hip.h: 1291 instructions per round (ISA count, r06), at most 18 rounds,
+// ~13 on random inputs (the wave leaves when every lane's a is zero) -- ~75 products' worth per thread, every lane of
+// the wave inverting its own product; Q amortises it (host side: Q grows with n, as long as every SIMD keeps two waves).
+struct BinvQuad {
+  Fr e[4];       // device form, 1 where the element is zero or beyond the end
+  bool live[4];  // a non-zero element inside the vector
+};
+PM_DEV BinvQuad binv_load(const u32x4* v, size_t n, size_t first, size_t T) {
+  BinvQuad q;
+  u32x4 lo[4], hi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                       // the four loads in flight together
+    const size_t i = first + (size_t)k * T;
+    lo[k] = hi[k] = u32x4{0u, 0u, 0u, 0u};
+    if (i < n) {
+      lo[k] = v[2 * i];
+      hi[k] = v[2 * i + 1];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 w[8] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w, hi[k].x, hi[k].y, hi[k].z, hi[k].w};
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) nz |= w[i];
+    q.live[k] = nz != 0;                             // (beyond the end: loaded as zero)
+    q.e[k] = q.live[k] ? abi_to_dev(fe_unpack<FrP>(w)) : fe_one<FrP>();
+  }
+  return q;
+}
+// MUL: out_i = mul_i / v_i instead of 1 / v_i (the prover's num / den of the permutation argument: one more product
+// per element here instead of a pass of its own over both vectors)
+template <bool MUL>
+__global__ void __launch_bounds__(256) batch_inverse_kernel(u32x4* v, const u32x4* mul, size_t n, u32 Q, u32x4* scratch) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const Fr one = fe_one<FrP>();
-  Fr acc = one;
-  for (u32 j = 0; j < L; ++j) {
-    const size_t i = t + (size_t)j * T;
-    if (i >= n) break;
-    const Fr raw = ld_canon(v, i);
-    u32 nz = 0;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) nz |= raw.l[q];
-    st_tw(scratch, i, acc);                    // product of the earlier non-zero elements
-    if (nz) acc = fe_mul<FrP>(acc, abi_to_dev(raw));
+  Fr acc = fe_one<FrP>();
+  for (u32 j = 0; j < Q; ++j) {
+    const size_t first = t + (size_t)(4 * j) * T;
+    if (first >= n) break;
+    const BinvQuad q = binv_load(v, n, first, T);
+    st_tw(scratch, (size_t)j * T + t, acc);     // product of everything before the quad
+    acc = fe_mul<FrP>(acc, fe_mul<FrP>(fe_mul<FrP>(q.e[0], q.e[1]), fe_mul<FrP>(q.e[2], q.e[3])));
   }
-  // 1 / acc by the binary GCD of field_inv.hip.h (~16 k instructions; r01 / r02: acc^(r-2), ~76 k and 57 % of a thread's
-  // work).  acc = x R' (device form): the integer inverse is x^-1 / R'; times R R'^2 (and the product's 1 / R') gives
-  // x^-1 R, the ABI form the back-substitution wants
+  // acc = x R' (device form): the integer inverse is x^-1 / R'; times R R'^2 (and the product's 1 / R') gives x^-1 R,
+  // the ABI form the back-substitution wants
   Fr inv = fe_mul<FrP>(fe_inv_int<FrP>(fe_canon_limbs<FrP>(acc)), fe_pow2<FrP, 256 + 2 * 261>());
-  for (u32 j = L; j-- > 0;) {
-    const size_t i = t + (size_t)j * T;
-    if (i >= n) continue;
-    const Fr raw = ld_canon(v, i);
-    u32 nz = 0;
+  for (u32 j = Q; j-- > 0;) {
+    const size_t first = t + (size_t)(4 * j) * T;
+    if (first >= n) continue;
+    const BinvQuad q = binv_load(v, n, first, T);
+    const Fr p01 = fe_mul<FrP>(q.e[0], q.e[1]), p23 = fe_mul<FrP>(q.e[2], q.e[3]);
+    const Fr iq = fe_mul<FrP>(inv, ld_tw(scratch, (size_t)j * T + t));   // 1 / E_j, ABI form
+    const Fr i01 = fe_mul<FrP>(iq, p23), i23 = fe_mul<FrP>(iq, p01);     // 1 / (e0 e1), 1 / (e2 e3)
+    Fr o[4] = {fe_mul<FrP>(i01, q.e[1]), fe_mul<FrP>(i01, q.e[0]), fe_mul<FrP>(i23, q.e[3]), fe_mul<FrP>(i23, q.e[2])};
+    if (MUL) {
+      Fr f[4];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) nz |= raw.l[q];
-    if (!nz) continue;                         // zero stays zero
-    st_canon(v, i, fe_mul<FrP>(inv, ld_tw(scratch, i)));   // a_i^-1, ABI form
-    inv = fe_mul<FrP>(inv, abi_to_dev(raw));
+      for (int k = 0; k < 4; ++k) f[k] = q.live[k] ? abi_to_dev(ld_canon(mul, first + (size_t)k * T)) : fe_one<FrP>();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = fe_mul<FrP>(o[k], f[k]);        // ABI x device stays ABI
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (q.live[k]) st_canon(v, first + (size_t)k * T, o[k]);           // zero stays zero; nothing beyond the end is live
+    inv = fe_mul<FrP>(inv, fe_mul<FrP>(p01, p23));
   }
 }
 
@@ -990,110 +943,47 @@ extern "C" int pm_fr_poly_ruffini_dev(pm_ctx* ctx, const void* d_coeffs, size_t 
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
   }
-  // one pass (see pm_fr_prefix_product_dev) while the tiles are few: this recurrence costs ~4.5 products per element in one
-  // pass (the powers of z every thread and every look-back lane needs) against 2.2 in three stages -- 2^16 69.7 -> 44.5 us,
-  // 2^18 87.2 -> 48.6, 2^19 67 -> 51, but 2^20 79 (the r05 hybrid below) against 94, 2^21 109 against 191: up to 1.5 tiles per CU
-  // (profiles/r03_poly_rows.txt, profiles/r05_poly_rows.txt)
-  const size_t lookback_max = ctx->opt_poly_lookback == 2 ? ((size_t)1 << 31) : (size_t)SC_TILE * 3 * (size_t)ctx->num_cus / 2;
-  if (ctx->opt_poly_lookback && m > (size_t)SC_TILE && m <= lookback_max) {
-    const u32 tiles = (u32)((m + SC_TILE - 1) / SC_TILE);
-    const size_t head = 64 + (size_t)tiles * 48;
-    OrderScope order_scope(ctx, ctx->ord_poly, st);
-    int rc = order_scope.rc;
-    if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, head);
-    if (rc) return rc;
-    RufLook lk2;
-    const HFr zt = hfr_pow_u64(zz, SC_TILE);
-    to_limbs29(lk2.z, zz);
-    to_limbs29(lk2.zt, zt);
-    to_limbs29(lk2.zt64, hfr_pow_u64(zt, 64));
-    const size_t lds = (size_t)SC_LDS_SLOTS * 16;
-    const void* fn = (const void*)ruf_lookback_kernel<false>;
-    if (int lrc = raise_lds_limit(ctx, fn, lds)) return lrc;
-    ProfScope prof(ctx, st, "fr_poly_ruffini");
-    PM_HIP(ctx, hipMemsetAsync(ctx->poly_ws.ptr, 0, head, st));
-    hipLaunchKernelGGL(ruf_lookback_kernel<false>, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (u32x4*)d_out,
-                       (u32*)ctx->poly_ws.ptr, tiles, lk2);
-    PM_HIP(ctx, hipGetLastError());
-    return PM_OK;
-  }
-  // level sizes: m, ceil(m / K), ... until one workgroup holds the level
-  // r05 (as for the prefix product): the descent stops at the first inner level whose tiles are all resident at once (this kernel:
-  // one workgroup per CU) and that level is scanned by ONE look-back launch (ruf_lookback_kernel<true>)
-  const size_t tw_resident = (size_t)SC_TILE * (size_t)ctx->num_cus;
-  std::vector<size_t> sz;
-  sz.push_back(m);
-  bool top_lookback = false;
-  while (sz.back() > (size_t)SC_BASE) {
-    sz.push_back((sz.back() + SC_K - 1) / SC_K);
-    if (ctx->opt_poly_lookback && sz.back() > (size_t)SC_BASE && sz.back() <= tw_resident) {
-      top_lookback = true;
-      break;
-    }
-  }
-  size_t tot_entries = 0;
-  for (size_t i = 1; i < sz.size(); ++i) tot_entries += sz[i];
-  if (sz.size() == 1) tot_entries = (m + SC_K - 1) / SC_K;       // a small input still goes totals -> base -> replay
-  const u32 top_tiles = top_lookback ? (u32)((sz.back() + SC_TILE - 1) / SC_TILE) : 0u;
-  const size_t lvl_bytes = (tot_entries * 48 + 64 + 255) / 256 * 256, ctl_bytes = top_lookback ? 64 + (size_t)top_tiles * 48 : 0;
+  // the scaled prefix sum (ruf_sum_*), every size: tables | chunk values + in-tile sums | tile carries | replay
+  const u32 tiles = (u32)((m + SC_TILE - 1) / SC_TILE);
+  const size_t tab_entries = 512 + 2 * (size_t)tiles, pre_entries = (size_t)tiles * 256;
   OrderScope order_scope(ctx, ctx->ord_poly, st);
   int rc = order_scope.rc;
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, lvl_bytes + ctl_bytes);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, (tab_entries + pre_entries + tiles) * 48);
   if (rc) return rc;
-  if (sz.size() == 1) sz.push_back((m + SC_K - 1) / SC_K);
-  std::vector<u32x4*> lvl(sz.size());
+  const host::Field<4>& F = host::FR();
+  const HFr z_inv = host::inv(zz, F);
+  RufSum rs;
+  to_limbs29(rs.z, zz);
+  to_limbs29(rs.one, host::one(F));
+  RufPowers rp;
   {
-    u32x4* p = (u32x4*)ctx->poly_ws.ptr;
-    for (size_t i = 1; i < sz.size(); ++i) {
-      lvl[i] = p;
-      p += 3 * sz[i];
-    }
+    const HFr zk_inv = hfr_pow_u64(z_inv, SC_K);
+    HFr b[4] = {zk_inv, hfr_pow_u64(zz, SC_K), hfr_pow_u64(z_inv, SC_TILE), hfr_pow_u64(zz, SC_TILE)};
+    for (int w_ = 0; w_ < 4; ++w_)
+      for (int j = 0; j < RUF_POW_BITS; ++j) {
+        to_limbs29(rp.p[w_][j], b[w_]);
+        b[w_] = host::mul(b[w_], b[w_], F);
+      }
+    to_limbs29(rp.pos_lo_scale, zk_inv);
   }
-  std::vector<RufLevel> zl(sz.size());
-  {
-    HFr zz_l = zz;
-    for (size_t i = 0; i < sz.size(); ++i) {
-      to_limbs29(zl[i].z, zz_l);
-      zz_l = hfr_pow_u64(zz_l, SC_K);
-    }
-  }
-  const size_t sc_lds_bytes = (size_t)SC_LDS_SLOTS * 16;
-  for (const void* fn : {(const void*)ruf_totals0_kernel, (const void*)ruf_replay0_kernel})
-    if (int lrc = raise_lds_limit(ctx, fn, sc_lds_bytes)) return lrc;
+  const size_t lds = (size_t)SC_LDS_SLOTS * 16;
+  for (const void* fn : {(const void*)ruf_sum_totals_kernel, (const void*)ruf_sum_replay_kernel<false>,
+                         (const void*)ruf_sum_replay_kernel<true>})
+    if (int lrc = raise_lds_limit(ctx, fn, lds)) return lrc;
+  u32x4* tab = (u32x4*)ctx->poly_ws.ptr;
+  u32x4* pre = tab + 3 * tab_entries;
+  u32x4* tot = pre + 3 * pre_entries;
   ProfScope prof(ctx, st, "fr_poly_ruffini");
-  const size_t last = sz.size() - 1;
-  for (size_t i = 0; i < last; ++i) {   // totals of level i -> level i + 1
-    const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
-    if (i == 0)
-      hipLaunchKernelGGL(ruf_totals0_kernel, dim3((unsigned)((m + SC_TILE - 1) / SC_TILE)), dim3(256), sc_lds_bytes, st,
-                         (const u32x4*)d_coeffs, n, m, lvl[1], zl[0]);
-    else
-      hipLaunchKernelGGL(ruf_totals_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)lvl[i], sz[i], lvl[i + 1],
-                         sz[i + 1], zl[i]);
-  }
-  if (top_lookback) {
-    u32* ctl = (u32*)((char*)ctx->poly_ws.ptr + lvl_bytes);
-    HFr zlast = zz;
-    for (size_t i = 0; i < last; ++i) zlast = hfr_pow_u64(zlast, SC_K);        // this level's multiplier z^(SC_K^last)
-    RufLook lk2;
-    const HFr zt = hfr_pow_u64(zlast, SC_TILE);
-    to_limbs29(lk2.z, zlast);
-    to_limbs29(lk2.zt, zt);
-    to_limbs29(lk2.zt64, hfr_pow_u64(zt, 64));
-    PM_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, st));
-    hipLaunchKernelGGL(ruf_lookback_kernel<true>, dim3(top_tiles), dim3(256), 0, st, (const u32x4*)lvl[last], sz[last], sz[last],
-                       lvl[last], ctl, top_tiles, lk2);
+  hipLaunchKernelGGL(ruf_sum_tables_kernel, dim3((unsigned)((tab_entries + 255) / 256)), dim3(256), 0, st, tab, rp, rs, tiles);
+  hipLaunchKernelGGL(ruf_sum_totals_kernel, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, pre, tot, rs,
+                     (const u32x4*)tab);
+  if (tiles > 512) {   // (the in-kernel sum of the tiles before costs ~1200 instructions per thread: worth a launch only while the tiles are few)
+    hipLaunchKernelGGL(ruf_sum_carry_kernel, dim3(1), dim3(256), 0, st, tot, tiles);
+    hipLaunchKernelGGL(ruf_sum_replay_kernel<false>, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (const u32x4*)pre,
+                       (const u32x4*)tot, (u32x4*)d_out, rs, (const u32x4*)tab, tiles);
   } else {
-    hipLaunchKernelGGL(ruf_base_kernel, dim3(1), dim3(256), 0, st, lvl[last], (u32)sz[last], zl[last]);
-  }
-  for (size_t i = last; i-- > 0;) {     // carries of level i + 1 -> outputs of level i
-    const unsigned blocks = (unsigned)((sz[i + 1] + 255) / 256);
-    if (i == 0)
-      hipLaunchKernelGGL(ruf_replay0_kernel, dim3((unsigned)((m + SC_TILE - 1) / SC_TILE)), dim3(256), sc_lds_bytes, st,
-                         (const u32x4*)d_coeffs, n, m, (const u32x4*)lvl[1], (u32x4*)d_out, zl[0]);
-    else
-      hipLaunchKernelGGL(ruf_replay_kernel, dim3(blocks), dim3(256), 0, st, lvl[i], sz[i], (const u32x4*)lvl[i + 1],
-                         sz[i + 1], zl[i]);
+    hipLaunchKernelGGL(ruf_sum_replay_kernel<true>, dim3(tiles), dim3(256), lds, st, (const u32x4*)d_coeffs, n, m, (const u32x4*)pre,
+                       (const u32x4*)tot, (u32x4*)d_out, rs, (const u32x4*)tab, tiles);
   }
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
@@ -1199,27 +1089,39 @@ extern "C" int pm_fr_prefix_product_dev(pm_ctx* ctx, const void* d_in, size_t n,
 }
 
 extern "C" int pm_fr_batch_inverse_dev(pm_ctx* ctx, void* d_inout, size_t n, void* hip_stream) {
+  return pm::fr_batch_inverse_mul(ctx, d_inout, nullptr, n, hip_stream);
+}
+// d_inout[i] <- d_mul[i] / d_inout[i] (d_mul == nullptr: 1 / d_inout[i]); zeros of d_inout stay zero
+int pm::fr_batch_inverse_mul(pm_ctx* ctx, void* d_inout, const void* d_mul, size_t n, void* hip_stream) {
   if (!ctx) return PM_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (n == 0) return PM_OK;
   if (!d_inout) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
   PM_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  // enough threads to fill the chip, at most 64 elements per thread
-  // one Fermat inversion (~380 products) per thread: 64 elements per thread amortise it to ~6
-  // products per element; below 2^22 elements keep at least one wave per SIMD instead
-  const size_t per = 32;   // elements per thread and inversion (2^22: 271 us with 32, 287 with 64, 318 with 16)
-  const size_t want_threads = std::max<size_t>((n + per - 1) / per, std::min<size_t>(n, (size_t)ctx->num_cus * 256));
+  // Quads per thread: the inversion (~75 products' worth of instructions, every lane inverting its own product) is amortised
+  // over 4 Q elements, against threads to fill the chip.  Measured (profiles/r06_binv_quads.txt, us per call):
+  //   2^20: Q = 2: 105, 4: 86, 8: 120      2^22: Q = 4: 267, 8: 212, 16: 204, 32: 332      2^24: Q = 16: 695, 32: 672, 64: 715
+  // i.e. one wave per SIMD (num_cus x 256 threads) up to Q = 16, Q = 32 beyond: amortising the inversion is worth more than
+  // the second wave's issue slots.  Option binv_quads overrides (tools/binv_bench.py).
+  size_t quads = (n + 3) / 4;
+  size_t Qw = ctx->opt_binv_quads > 0 ? (size_t)ctx->opt_binv_quads
+                                      : std::min<size_t>(32, std::max<size_t>(1, quads / ((size_t)ctx->num_cus * 256)));
+  const size_t want_threads = (quads + Qw - 1) / Qw;
   const unsigned blocks = (unsigned)((want_threads + 255) / 256);
   const size_t T = (size_t)blocks * 256;
-  const u32 L = (u32)((n + T - 1) / T);
+  const u32 Q = (u32)((n + 4 * T - 1) / (4 * T));
   OrderScope order_scope(ctx, ctx->ord_poly, st);
   int rc = order_scope.rc;
-  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, n * 48);
+  if (!rc) rc = ensure_buffer(ctx, ctx->poly_ws, (size_t)Q * T * 48);     // one entry per quad
   if (rc) return rc;
   ProfScope prof(ctx, st, "fr_batch_inverse");
-  hipLaunchKernelGGL(batch_inverse_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)d_inout, n, L,
-                     (u32x4*)ctx->poly_ws.ptr);
+  if (d_mul)
+    hipLaunchKernelGGL(batch_inverse_kernel<true>, dim3(blocks), dim3(256), 0, st, (u32x4*)d_inout, (const u32x4*)d_mul, n, Q,
+                       (u32x4*)ctx->poly_ws.ptr);
+  else
+    hipLaunchKernelGGL(batch_inverse_kernel<false>, dim3(blocks), dim3(256), 0, st, (u32x4*)d_inout, (const u32x4*)nullptr, n, Q,
+                       (u32x4*)ctx->poly_ws.ptr);
   PM_HIP(ctx, hipGetLastError());
   return PM_OK;
 }

@@ -800,11 +800,10 @@ static int prove_body(pm_ctx* ctx, pm_prover_key* pk, const pm_bases* ck, const 
   put(pa.gamma, gamma);
   for (int j = 0; j < 3; ++j) put(pa.k[j], pk->k[j]);
   PK_TRY(pm_plonk_perm_terms_dev(ctx, &pa, n, pk->num, pk->den, nullptr));
-  PK_TRY(pm_fr_batch_inverse_dev(ctx, pk->den, n, nullptr));
-  PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->num, pk->den, n, pk->num, n, nullptr));
-  PK_TRY(pm_fr_prefix_product_dev(ctx, pk->num, n, pk->den, nullptr));
+  PK_TRY(pm::fr_batch_inverse_mul(ctx, pk->den, pk->num, n, nullptr));       // den <- num / den (r06: one kernel, was two)
+  PK_TRY(pm_fr_prefix_product_dev(ctx, pk->den, n, pk->num, nullptr));       // num <- z on H
   void* z_coeffs = at(pk->coeffs, 4 * n);
-  PK_TRY(pm_fr_ntt_dev(ctx, pk->den, n, n, z_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
+  PK_TRY(pm_fr_ntt_dev(ctx, pk->num, n, n, z_coeffs, n, lg, 1, PM_NTT_INVERSE, nullptr));
   // z on the 4n coset depends on no further challenge: side stream, under the commitment to z
   PK_TRY(pm_stream_fork(ctx, side, pk->ev_main));
   PK_TRY(pm_fr_ntt_dev(ctx, z_coeffs, n, n, at(pk->coset, 4 * n * 4), 4 * n, lg + 2, 1, PM_NTT_COSET, side));

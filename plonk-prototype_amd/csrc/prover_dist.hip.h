@@ -484,23 +484,22 @@ static int prove_dist_body(pm_ctx* ctx, Dist& D, pm_dist_key* pk, const pm_bases
   put(pa.gamma, gamma);
   for (int j = 0; j < 3; ++j) put(pa.k[j], pk->k[j]);
   PK_TRY(pm_plonk_perm_terms_dev(ctx, &pa, m, pk->num, pk->den, nullptr));
-  PK_TRY(pm_fr_batch_inverse_dev(ctx, pk->den, m, nullptr));
-  PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->num, pk->den, m, pk->num, m, nullptr));
-  PK_TRY(pm_fr_prefix_product_dev(ctx, pk->num, m, pk->den, nullptr));   // den[i] = product of this rank's num[0 .. i)
+  PK_TRY(pm::fr_batch_inverse_mul(ctx, pk->den, pk->num, m, nullptr));    // den[i] <- num[i] / den[i]
+  PK_TRY(pm_fr_prefix_product_dev(ctx, pk->den, m, pk->num, nullptr));   // num[i] = product of this rank's ratios [0 .. i)
   {
-    // the product of the whole slice = den[m - 1] num[m - 1]; every rank's goes round, the ranks below give the carry
+    // the product of the whole slice = num[m - 1] den[m - 1]; every rank's goes round, the ranks below give the carry
     u64 last[2][4];
-    PK_TRY(pm_dev_download(ctx, last[0], at(pk->den, m - 1), 32));
-    PK_TRY(pm_dev_download(ctx, last[1], at(pk->num, m - 1), 32));
+    PK_TRY(pm_dev_download(ctx, last[0], at(pk->num, m - 1), 32));
+    PK_TRY(pm_dev_download(ctx, last[1], at(pk->den, m - 1), 32));
     const HFr total = fmul(get(last[0]), get(last[1]));
     std::vector<HFr> all;
     PK_TRY(dist_scalars(ctx, D, &total, 1, all));
     HFr carry = one;
     for (uint32_t r = 0; r < rk; ++r) carry = fmul(carry, all[r]);
     PK_TRY(upload_scalar(ctx, pk, carry));
-    PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->den, pk->scalar, 1, pk->den, m, nullptr));
+    PK_TRY(pm_fr_vec_op_dev(ctx, 2, pk->num, pk->scalar, 1, pk->num, m, nullptr));
   }
-  PM_HIP(ctx, hipMemcpyAsync(z_coeffs, pk->den, m * 32, hipMemcpyDeviceToDevice, st));
+  PM_HIP(ctx, hipMemcpyAsync(z_coeffs, pk->num, m * 32, hipMemcpyDeviceToDevice, st));
   PK_TRY(dist_ntt(ctx, D, pk, z_coeffs, 1, nullptr, PM_NTT_INVERSE));
   {
     const void* src[1] = {z_coeffs};
