@@ -471,6 +471,19 @@ int pm_comm_info(const pm_ctx* ctx, int* rank, int* world);
 int pm_g1_allgather_fold(pm_ctx* ctx, uint64_t* xyz, uint32_t k);
 /* test hook: the fold step on `world` messages of 1 + 16 x 18 words ([count | points]) given by the caller */
 int pm_test_fold_gathered(const uint64_t* msgs, int world, uint32_t k, uint64_t* out_xyz);
+/* A dead peer INSIDE an exchange: pm_set_option(ctx, "comm_timeout_ms", T) with T > 0 (default 0 = off) puts every exchange
+ * on the context's communicator -- the message all-gather and the all-to-all of the rank-split transform -- under a
+ * deadline that covers both the enqueue and the wait for its completion (with the option on, an all-to-all is waited
+ * for where it is issued).  When T ms pass without completion the context's watch thread calls ncclCommAbort, the
+ * blocked call returns, the entry point returns PM_ERR_EXCHANGE (pm_last_error names the exchange and the option) and
+ * the communicator is DEAD: every later exchange on it returns PM_ERR_EXCHANGE at once, until pm_comm_destroy +
+ * pm_comm_init on every rank.  Choose T well above the slowest legitimate exchange (the peers of a 2^24-gate proof
+ * arrive at their all-gathers tens of milliseconds apart; a first all-to-all also sets up connections).  The callback
+ * transports have their own containment (a broken barrier).  Test hook, no GPU and no RCCL: the same deadline logic on a
+ * stub table whose all-gather blocks until its communicator is aborted (peer_answers = 0) or returns at once (1):
+ * first_rc / second_rc = two exchanges in a row, elapsed_ms = the first one's duration, aborts = ncclCommAbort calls. */
+int pm_test_comm_deadline(long timeout_ms, int peer_answers, int* first_rc, long* elapsed_ms, int* second_rc, int* aborts,
+                          char* err_out, size_t err_cap);
 
 /* Keccak-f[1600] on a 200-byte state (host; the permutation under the Merlin / STROBE-128 transcript
  * the prover derives its challenges from -- merlin is a dependency of dusk-plonk, ref:Cargo.toml:19). */

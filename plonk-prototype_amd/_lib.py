@@ -141,6 +141,8 @@ SIGNATURES = {
     "pm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pm_g1_allgather_fold": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
     "pm_test_fold_gathered": (C.c_int, [u64p, C.c_int, C.c_uint32, u64p]),
+    "pm_test_comm_deadline": (C.c_int, [C.c_long, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "pm_keccak_f1600": (None, [C.c_char_p]),
     "pm_ntt_plan": (C.c_int, [C.c_uint32, u32p, u32p]),
     "pm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),

@@ -294,6 +294,11 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
     ctx->opt_poly_lookback = value;
     return PM_OK;
   }
+  if (!strcmp(key, "comm_timeout_ms")) {
+    if (value < 0 || value > 86400000L) return set_err(ctx, PM_ERR_BAD_ARG, "comm_timeout_ms must be 0 (off) .. 86400000");
+    ctx->opt_comm_timeout_ms = value;
+    return PM_OK;
+  }
   if (!strcmp(key, "binv_quads")) {
     if (value < 0 || value > 1024) return set_err(ctx, PM_ERR_BAD_ARG, "binv_quads must be 0 (auto) .. 1024");
     ctx->opt_binv_quads = value;

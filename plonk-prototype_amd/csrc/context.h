@@ -12,6 +12,9 @@
 
 namespace pm {
 
+class ExchangeWatch;                                    // comm.hip
+void exchange_watch_free(ExchangeWatch* w);
+
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;
@@ -80,6 +83,8 @@ struct pm_ctx {
   size_t msm_host_pinned_bytes = 0;
   // multi-GPU exchange (comm.hip): RCCL communicator of this rank, device and pinned staging buffers
   void* comm = nullptr;
+  bool comm_dead = false;                               // an exchange timed out and the communicator was aborted (comm.hip)
+  pm::ExchangeWatch* comm_watch = nullptr;              // the deadline thread of guarded exchanges (option comm_timeout_ms)
   int comm_rank = 0, comm_world = 1;
   void *comm_send = nullptr, *comm_recv = nullptr, *comm_host = nullptr;
   // opt-in per-kernel timing (hipEvents on the launch stream; read by bench.py)
@@ -107,6 +112,7 @@ struct pm_ctx {
   long opt_msm_chunk = 0;        // 0 = auto (entries per thread in the level-1 accumulate)
   long opt_msm_max_pairs = 0;    // 0 = 2^31 - 1; a batched MSM with more (digit, point) pairs runs in halves
   long opt_msm_lb = 0;           // 0 = auto (buckets per thread in the bucket reduce)
+  long opt_comm_timeout_ms = 0;  // > 0: every exchange on the context's RCCL communicator runs under this deadline (comm.hip)
   long opt_binv_quads = 0;       // batch inversion: quads (4 elements) per thread and inversion; 0 = auto
   long opt_poly_lookback = 1;    // prefix product in one pass (decoupled look-back) instead of totals / scan / replay
   long opt_msm_pipeline = 0;     // 1: a batched MSM runs as up to four pieces on two streams (measured: loses, see msm.hip)

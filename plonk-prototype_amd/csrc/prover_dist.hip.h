@@ -21,9 +21,12 @@
 // r04 made 3 per transform x 34 transforms = 102 (pm_comm_stats counts them).  Prefix product, openings and Ruffini division
 // are local passes plus one fixed-size all-gather of per-rank scalars each.  Every exchange besides the all-to-all is
 // the SAME 2312-byte message all-gather as the sharded prover's (count word 0 = abort marker): 8 per proof, the first an
-// agreement on the arguments: a rank whose arguments are bad meets its peers there with the marker.  (A rank that fails
-// LATER, between two all-to-alls -- a HIP error, an allocation -- returns its error; its peers see the marker at their next
-// all-gather but cannot see it inside an all-to-all: treat such an error as fatal for the group.)
+// agreement on the arguments: a rank whose arguments are bad meets its peers there with the marker.  A rank that fails
+// LATER, between two all-to-alls -- a HIP error, an allocation, a dead process -- returns its error (or nothing); its peers
+// see the marker at their next all-gather but cannot see it inside an all-to-all.  Containment (r06): with option
+// comm_timeout_ms set, the peers' pending exchange is ended by ncclCommAbort after the deadline, their call returns
+// PM_ERR_EXCHANGE and their communicator is marked dead (comm.hip); without the option they block until the host's own
+// watchdog ends them.
 // Results are bit-identical to pm_plonk_prove (tests/test_gpu_dist_prover_n5.py).
 
 static constexpr uint32_t DIST_MAX_VECS = 20;   // vectors of one batched transform (5 polynomials x 4 sub-cosets): sizes the stage buffer

@@ -147,14 +147,19 @@ def test_one_rank_failing_outside_an_msm_does_not_block_its_peer(mode):
         assert res[0][1] == 1040 and res[1][1] == 1040
 
 
-def test_library_communicator_world1(ctx, oracle):
+@pytest.mark.parametrize("timeout_ms", [0, 20000])
+def test_library_communicator_world1(ctx, oracle, timeout_ms):
     """The in-library RCCL exchange on the one GPU of the test box (a one-rank communicator: two RCCL ranks
     cannot share a device): unique id, ncclCommInitRank, ncclAllGather through pm_g1_allgather_fold, and the
-    sharded prover entry points with exchange = NULL -- the proof must equal the unsharded one byte for byte."""
+    sharded prover entry points with exchange = NULL -- the proof must equal the unsharded one byte for byte.
+    timeout_ms > 0: the same with every exchange under the deadline of option comm_timeout_ms (the watch thread armed and
+    disarmed around the real ncclAllGather; exchanges that complete are left alone -- tests/test_comm_deadline.py has the
+    other case, on a stub table)."""
     import plonk_prototype_amd as pa
     from plonk_prototype_amd.dist import ShardedCommitKey
     from oracle.cpu_oracle import ints_to_limbs
     circuit, wit, pi, srs = _inputs()
+    ctx.set_option("comm_timeout_ms", timeout_ms)
     ctx.comm_init(0, 1)
     try:
         part = np.zeros((2, 18), np.uint64)
@@ -173,5 +178,6 @@ def test_library_communicator_world1(ctx, oracle):
         assert pa.prove(pk, ck, wit, pi).to_bytes() == ref.to_bytes()
     finally:
         ctx.comm_destroy()
+        ctx.set_option("comm_timeout_ms", 0)
     with pytest.raises(pa.Error):
         ctx.g1_allgather_fold(np.zeros((1, 18), np.uint64))          # no communicator any more
