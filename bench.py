@@ -36,13 +36,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
 
 
+PMC_ROUND = "r06"          # the round whose committed PMC summaries describe THIS tree's kernels
+
+
 def pmc_traffic(kernel, grid=None, also=(), kinds=("pmc_summary", "pmc_prover_summary", "pmc_big_summary")):
     """HBM bytes per launch of `kernel` from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of
     MI355X_MICROARCH.md) -> (bytes, source) or (None, None).  The counters cannot be collected inside this process: the PMC
     passes are separate `rocprofv3 --pmc` runs (tools/collect_pmc.sh -> tools/pmc_summary.py) whose summaries are committed under
-    profiles/; the newest round that has the kernel (at this grid, when given; every string of `also` in the entry's name) is quoted."""
+    profiles/.  Only the CURRENT round's summaries are quoted as they stand (a kernel whose tiling changed must not
+    report an older kernel's bytes as its own); when this round has none yet, the previous round's figure is returned with its
+    source string marked "STALE rNN" -- the caller passes the string through, so the line says what it is.  Several entries
+    at different grids and no grid asked for: the largest grid (the full-size launch) is taken."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r05", "r04"):
+    for rnd in (PMC_ROUND, "r05"):
         for kind in kinds:
             path = os.path.join(root, f"{rnd}_{kind}.json")
             try:
@@ -53,9 +59,19 @@ def pmc_traffic(kernel, grid=None, also=(), kinds=("pmc_summary", "pmc_prover_su
             hits = [(nm, e) for nm, e in ents.items()
                     if kernel in nm and all(a in nm for a in also) and "hbm_bytes_per_launch_corrected" in e
                     and (grid is None or f"grid={grid} " in nm + " ")]
-            if len(hits) == 1 or (hits and grid is not None):
-                nm, e = hits[0]
-                return int(e["hbm_bytes_per_launch_corrected"]), f"profiles/{rnd}_{kind}.json [{nm}]"
+            if not hits:
+                continue
+
+            def grid_of(nm_):
+                try:
+                    return int(nm_.split("grid=")[1].split()[0])
+                except (IndexError, ValueError):
+                    return 0
+            nm, e = max(hits, key=lambda h_: grid_of(h_[0]))
+            src = f"profiles/{rnd}_{kind}.json [{nm}]"
+            if rnd != PMC_ROUND:
+                src = f"STALE {rnd} (no {PMC_ROUND} summary has this kernel; the kernel may have changed since): " + src
+            return int(e["hbm_bytes_per_launch_corrected"]), src
     return None, None
 
 
@@ -474,7 +490,7 @@ def main():
     prof_avg, prof_src = None, None
     try:
         import csv
-        for rnd_ in ("r05", "r04"):
+        for rnd_ in (PMC_ROUND, "r05"):
             path_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd_}_headline_kernel_stats.csv")
             if not os.path.exists(path_):
                 continue

@@ -168,7 +168,10 @@ int pm_fr_ntt_fourstep_dev(pm_ctx* ctx, void* d_inout, void* d_stage, uint32_t l
  * 2^(log_n - log_n / 2): vector v's copy of the FIRST ROW OF THE NEXT RANK's part of the block-transposed result (row 0 for the
  * last rank), i.e. the values at index + 1 of this rank's last row -- what a consumer that reads X[k + 1] beside X[k] (the
  * quotient's z(w X) and next-row wires) needs from its neighbour; it travels inside the second all-to-all as one more column
- * per peer, no exchange of its own.  d_stage then holds 2 x batch x (N/world + N2) elements.
+ * per peer, no exchange of its own.  d_stage then holds 2 x batch x (N/world + N2) elements -- with world == 1:
+ * batch x (N + N2): the halo row is packed there too.  The call cannot check the size of d_stage: the caller sizes it by this
+ * rule (the library's own caller, csrc/prover_dist.hip.h, allocates 2 x 20 x (m + n2) elements once per key).  d_halo
+ * doubles as the halo switch: a non-NULL d_halo on a call that is not forward + PM_NTT_TRANSPOSED is PM_ERR_BAD_ARG.
  * pm_fr_ntt_fourstep_dev is this call with batch = 1 and no halo. */
 int pm_fr_ntt_fourstep_batch_dev(pm_ctx* ctx, void* d_inout, uint32_t batch, void* d_halo, void* d_stage, uint32_t log_n,
                                  uint32_t world, uint32_t rank, uint32_t flags, pm_alltoall_fn exchange, void* user);

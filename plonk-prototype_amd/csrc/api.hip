@@ -340,6 +340,19 @@ extern "C" int pm_set_option(pm_ctx* ctx, const char* key, long value) {
 extern "C" int pm_test_host_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   if (!a || !out || op < 0 || op > 5 || (op < 2 && !b)) return PM_ERR_BAD_ARG;
   using namespace pm::host;
+  {
+    // operands are field elements: canonical limbs (< m).  The host code relies on it everywhere; this is where it is asserted
+    const bool fp = op & 1;
+    const int N = fp ? 6 : 4;
+    const uint64_t* m = fp ? FP().m : FR().m;
+    auto canonical = [&](const uint64_t* x) {
+      for (int l = N - 1; l >= 0; --l)
+        if (x[l] != m[l]) return x[l] < m[l];
+      return false;
+    };
+    for (size_t i = 0; i < n; ++i)
+      if (!canonical(a + N * i) || (op < 2 && !canonical(b + N * i))) return PM_ERR_BAD_ARG;
+  }
   for (size_t i = 0; i < n; ++i) {
     if (op == 0 || op == 2 || op == 4) {
       HFr x, y;

@@ -223,17 +223,9 @@ PM_DEV Fe<P> fe_norm_full(const Fe<P>& a) {
 // not adopted there: the shift split into v_alignbit_b32 + 32-bit shift (VOP3 issues like the 64-bit shift), "+q"
 // through a mad, and for Fr the subtractive digit q' = acc mod 2^W with a signed accumulator (-2 % more at four
 // waves per SIMD, but it needs Ba * Bb < 3.5 where the NTT butterflies hand fe_mul limbs up to 5 * 2^29).
-// `make EXTRA=-DPM_FE_CHAIN=0` builds the r04 forms for A/B runs.
-#ifndef PM_FE_CHAIN
-#define PM_FE_CHAIN 1
-#endif
-#if PM_FE_CHAIN
+// The r04 form (no chain, q added as a value) lives only where the A/B does: tools/fe_chain.hip.h, tools/fe_mul_chain_ab.hip.
 #define PM_KEEP(tok, x) asm("" : "+v"(tok) : "v"(x))
 #define PM_KEEP_INIT(tok) asm("" : "=v"(tok))
-#else
-#define PM_KEEP(tok, x)
-#define PM_KEEP_INIT(tok) tok = 0
-#endif
 PM_DEV void fe_mac(u64& acc, u32 a, u32 b, u32& tok) {
   acc += (u64)a * b;
   PM_KEEP(tok, acc);
@@ -267,11 +259,7 @@ PM_DEV void fe_mont_cols(F&& prod, Fe<P>* const (&r)[K]) {
       for (int c = 0; c < K; ++c) {
         if (M.v[0] == 1u) {  // Fr: m = 1 mod 2^W, -m^-1 = -1
           q[c][k] = (0u - (u32)acc[c]) & MASK;
-#if PM_FE_CHAIN
           acc[c] += (u64)MASK;  // (acc + q) >> W == (acc + 2^W - 1) >> W: the carry does not wait for q
-#else
-          acc[c] += q[c][k];
-#endif
         } else {
           q[c][k] = ((u32)acc[c] * NINV) & MASK;
           fe_mac(acc[c], q[c][k], M.v[0], tok);
@@ -292,9 +280,7 @@ PM_DEV void fe_mont_cols(F&& prod, Fe<P>* const (&r)[K]) {
   }
 #pragma unroll
   for (int c = 0; c < K; ++c) r[c]->l[N - 1] = (u32)acc[c];
-#if PM_FE_CHAIN
   asm("" : "+v"(r[0]->l[N - 1]) : "v"(tok));  // the token chain ends in a live value
-#endif
 }
 // limb products a_i b_(k-i) of column k
 template <class P>

@@ -192,6 +192,15 @@ inline El<N> inv(const El<N>& a, const Field<N>& F) {
   u64 u[N], v[N], x1[N], x2[N];
   memcpy(u, a.l, sizeof u);
   memcpy(v, F.m, sizeof v);
+  // a representative >= m (never produced by this library: every El is canonical) is reduced first; a multiple of m is
+  // 0 in the field -> 0, like the exponentiation gave.  Without this u reaches 0 below and the halving loop never ends
+  // (ADVICE r05).
+  while (geq<N>(u, v)) sub_n<N>(u, u, v);
+  {
+    u64 any = 0;
+    for (int i = 0; i < N; ++i) any |= u[i];
+    if (!any) return El<N>{};
+  }
   memset(x1, 0, sizeof x1);
   memset(x2, 0, sizeof x2);
   x1[0] = 1;

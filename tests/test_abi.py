@@ -132,6 +132,16 @@ def test_host_field_arithmetic_against_big_integers():
             for v, g in zip(vals, limbs_to_ints(out)):
                 assert g == (pow(v, -1, mod) * Rm % mod if v else 0), (nl, op, v)
     assert lib.pm_test_host_field_op(9, p(a), None, p(out), 1) == -1
+    # operands must be canonical: a == m (congruent to 0) and values above m are refused, not looped on (the binary
+    # Euclid did not terminate on a non-zero multiple of m)
+    for nl, mod, ops in ((4, B.R_MOD, (0, 2, 4)), (6, B.P_MOD, (1, 3, 5))):
+        good = ints_to_limbs([5], nl)
+        for bad_v in (mod, mod + 1, (1 << (64 * nl)) - 1):
+            bad = ints_to_limbs([bad_v], nl)
+            out1 = np.zeros_like(bad)
+            for op in ops:
+                assert lib.pm_test_host_field_op(op, p(bad), p(good), p(out1), 1) == -1
+            assert lib.pm_test_host_field_op(ops[0], p(good), p(bad), p(out1), 1) == -1
 
 
 def test_integration_doc_lists_every_export():

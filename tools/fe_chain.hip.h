@@ -23,6 +23,7 @@
 
 namespace pm {
 
+#undef PM_KEEP   // (fields.hip.h has the token-threaded two-argument form of the adopted product)
 #define PM_KEEP(x) asm volatile("" ::"v"(x))
 template <bool ASM>
 PM_DEV void mad_vv(u64& acc, u32 a, u32 b) {

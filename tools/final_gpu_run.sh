@@ -2,11 +2,14 @@
 # One consolidated GPU validation (run through gpurun): tests, bench, smoke, rocprof stats, PMC.
 # Everything is written under gpurun_out/$1/; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r05z}
+TAG=${1:-r06z}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
+# an optional step: its failure does not stop the run, but leaves FILE.failed beside the output so that refresh_profiles.sh
+# does not copy a shell error into profiles/ as if it were evidence (profiles/r05_sort_bench.txt was one)
+opt() { local f=$1 t=$2; shift 2; rm -f $OUT/$f.failed; timeout -k 10 $t "$@" > $OUT/$f 2>&1 || echo "rc=$? cmd=$*" > $OUT/$f.failed; true; }
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1 && \
 bash tools/collect_pmc.sh $TAG > $OUT/collect_pmc.log 2>&1 && \
 python tools/pmc_summary.py gpurun_out/$TAG $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1 && \
@@ -14,11 +17,14 @@ python tools/pmc_summary.py gpurun_out/$TAG $OUT/pmc_prover_summary.json prv_ > 
 python tools/pmc_summary.py gpurun_out/$TAG $OUT/pmc_big_summary.json big_ > $OUT/pmc_big_summary.txt 2>&1 && \
 timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err && \
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1 && \
-(timeout -k 10 300 ./tools/sort_bench > $OUT/sort_bench.txt 2>&1; true) && \
-(timeout -k 10 300 python tools/poly_rows.py 22 10 > $OUT/poly_rows.txt 2>&1; true) && \
-(timeout -k 10 300 python tools/prover_bench.py 20 7 > $OUT/prover20.txt 2>&1; true) && \
-(timeout -k 10 200 python tools/small_proof_c_sweep.py 10,11,12,13,14,15,16,17 0 > $OUT/small_proofs.txt 2>&1; true) && \
-(timeout -k 10 200 python tools/proof_latency_trace.py > $OUT/proof_latency_trace.txt 2>&1; true) && \
+opt poly_rows.txt 300 python tools/poly_rows.py 22 10 && \
+opt poly_rows_2p20.txt 300 python tools/poly_rows.py 20 10 && \
+opt binv_quads.txt 300 python tools/binv_bench.py && \
+opt ruffini.txt 300 python tools/ruffini_ab.py && \
+opt prover20.txt 300 python tools/prover_bench.py 20 7 && \
+opt prover24.txt 400 python tools/prover_bench.py 24 3 wide && \
+opt small_proofs.txt 200 python tools/small_proof_c_sweep.py 10,11,12,13,14,15,16,17 0 && \
+opt proof_latency_trace.txt 200 python tools/proof_latency_trace.py && \
 (cd /tmp && export TMPDIR=/tmp && \
  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/bench.py --steps 200 --no-cpu-baseline --no-msm --no-poly --no-prover --no-ntt-extra > $OUT/stats_headline.json 2> $OUT/stats_headline.err && \
  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --no-cpu-baseline --msm-large-log-n 0 --no-poly --no-ntt-extra > $OUT/stats_bench.json 2> $OUT/stats.err && \
