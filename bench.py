@@ -1006,6 +1006,13 @@ def main():
         # prices the decomposition itself (four size-n sub-coset transforms per coset form, each through the four-step
         # transform with one rank); N > 1 is the real thing -- the library's RCCL all-gather and all-to-all
         dist_leg = None
+        # what has finished so far goes into the line's legs NOW: if the distributed leg below hangs in its first real all-to-all
+        # (N > 1: never executed before the first multi-GPU run), the watchdog's line still carries the sharded prover's figures
+        legs["prover"] = {"gates": gn, "ms_per_proof": round(pdt * 1e3, 2), "gates_per_s": gn / pdt, "n_gpus": world,
+                          "entry_point": "pm_plonk_prove" if world == 1 else "pm_plonk_prove_sharded",
+                          "kernel_ms": {k_: round(v_, 3) for k_, v_ in grp.items()},
+                          "verifier_identity_holds": ident_ok, "commitment_matches_dlog": comm_ok,
+                          "note": "partial entry: the legs after this one (pm_plonk_prove_dist, two contexts, ...) had not finished"}
         if not args.no_dist_prover and gn % (world * world) == 0:
             # Every phase that holds collectives runs under try / except on every rank and is followed by an agreement
             # (all_reduce MIN, which every rank reaches): a rank whose phase failed never leaves its peers waiting in a
@@ -1292,6 +1299,7 @@ def main():
             lck = ShardedCommitKey.setup(ln, tau, rank * m_l, (rank + 1) * m_l, ctx, precompute=True, native=native_comm,
                                          device=coll_dev)
             l_bases = lck._bases
+        prover["large"] = large                               # (the watchdog's line carries what has finished: legs["prover"] is this dict)
         dl_leg, err, dkey, d_wsl, dproof, d_times, t_dpre, dstats = None, None, None, None, None, [], 0.0, {}
         if not args.no_dist_prover:
             try:

@@ -18,22 +18,21 @@ for k in sizes:
     host[5] = 0
     host[n - 3] = 0
     v = pa.DeviceVector.from_host(ctx, host)
-    # check once: a * a^-1 = 1 on the non-zero entries, zeros stay
-    ctx.fr_batch_inverse(v.ptr, n)
-    prod = pa.DeviceVector.from_host(ctx, host)
-    ctx.fr_vec_op(2, prod.ptr, v.ptr, n, prod.ptr, n)
-    got = prod.to_host()
+    orig = pa.DeviceVector.from_host(ctx, host)
+    prod = pa.DeviceVector(ctx, n)
     one = orc.fr_to_mont(np.array([[1, 0, 0, 0]], np.uint64))[0]
     exp = np.tile(one, (n, 1))
     exp[5] = 0
     exp[n - 3] = 0
-    ok = np.array_equal(got, exp)
-    prod.free()
     for q in (0, 1, 2, 4, 8, 16, 32, 64):
         if 4 * q > n:
             continue
         ctx.set_option("binv_quads", q)
+        # check this configuration: a * a^-1 = 1 on the non-zero entries, zeros stay
+        ctx._check(ctx._lib.pm_dev_upload(ctx._h, v._p, host.ctypes.data, n * 32))
         ctx.fr_batch_inverse(v.ptr, n)
+        ctx.fr_vec_op(2, orig.ptr, v.ptr, n, prod.ptr, n)
+        ok = np.array_equal(prod.to_host(), exp)
         ctx.sync()
         ctx.profile(True)
         for _ in range(5):
@@ -45,3 +44,5 @@ for k in sizes:
         print(f"2^{k} Q={q:3d}  {us:9.1f} us  {64 * n / us / 1e3:8.1f} GB/s  {64 * n / us / 1e3 / 8000:.4f} of HBM   ok={ok}", flush=True)
     ctx.set_option("binv_quads", 0)
     v.free()
+    orig.free()
+    prod.free()
