@@ -43,16 +43,15 @@ def test_evaluate(ctx, oracle, n):
 @pytest.mark.parametrize("n", [1, 2, 3, 256, 257, 258, 2048, 2049, 2050, 4097, 5000, (1 << 16) + 1, (1 << 20) + 5, (1 << 21) + 3,
                                (1 << 22) + 1, (1 << 22) + 77, (1 << 23) + 5])
 def test_ruffini(ctx, oracle, n):
+    """(r06: one scheme for every size -- the scaled prefix sum; the tile carries are summed inside the replay kernel up to 512
+    tiles = 2^20 elements and by a kernel of their own beyond, in sweeps of 2048 tiles: 2^22 + 77 and 2^23 + 5 take two and three.
+    z = 1 and z = -1 make every power table entry +-1; z = 0 is the shift.)"""
     c = oracle.fr_sample(7 + n, n)
-    try:
-        for mode in (1, 0, 2):                            # the library's choice, the three-stage scan, the one-pass look-back
-            ctx.set_option("poly_lookback", mode)
-            for z in (oracle.fr_sample(9, 1)[0], np.zeros(4, np.uint64), oracle.fr_to_mont(ints_to_limbs([1], 4))[0]):
-                q = _poly(ctx, c).ruffini(z).to_host()
-                assert q.shape[0] == n - 1
-                assert np.array_equal(q, oracle.fr_poly_ruffini(c, z)), (n, mode)
-    finally:
-        ctx.set_option("poly_lookback", 1)
+    for z in (oracle.fr_sample(9, 1)[0], np.zeros(4, np.uint64), oracle.fr_to_mont(ints_to_limbs([1], 4))[0],
+              oracle.fr_to_mont(ints_to_limbs([B.R_MOD - 1], 4))[0]):
+        q = _poly(ctx, c).ruffini(z).to_host()
+        assert q.shape[0] == n - 1
+        assert np.array_equal(q, oracle.fr_poly_ruffini(c, z)), n
     if n > 1:   # q(X) (X - z) + c(z) == c(X) at a random point (the defining identity)
         z = oracle.fr_sample(9, 1)[0]
         q = _poly(ctx, c).ruffini(z)
@@ -63,8 +62,19 @@ def test_ruffini(ctx, oracle, n):
         assert (qx * (xv - zv) + cz) % B.R_MOD == cx
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1 << 16, (1 << 18) + 11])
-def test_batch_inverse(ctx, oracle, n):
+@pytest.mark.parametrize("n,quads", [(1, 0), (2, 0), (3, 1), (63, 0), (64, 0), (65, 0), (1000, 0), (1000, 3), (5000, 7), (1 << 16, 0),
+                                     (1 << 16, 2), ((1 << 18) + 11, 0), ((1 << 18) + 11, 64), ((1 << 20) + 3, 0), ((1 << 22) + 5, 0)])
+def test_batch_inverse(ctx, oracle, n, quads):
+    """quads: option binv_quads (0 = the library's rule: one quad per thread up to 2^18 elements, 4 at 2^20, 16 at 2^22) -- small
+    sizes with several quads per thread exercise the scratch chain between the quads and ragged last quads."""
+    ctx.set_option("binv_quads", quads)
+    try:
+        _batch_inverse_case(ctx, oracle, n)
+    finally:
+        ctx.set_option("binv_quads", 0)
+
+
+def _batch_inverse_case(ctx, oracle, n):
     a = oracle.fr_sample(11 + n, n)
     a[:: max(1, n // 7)] = 0                                       # zeros stay zero
     if n > 5:

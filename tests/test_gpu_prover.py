@@ -637,6 +637,33 @@ def test_prove_matches_the_c_prover(ctx, oracle, log_n, mixed):
         assert np.array_equal(pk.verifier_key[k], v), k
 
 
+@pytest.mark.parametrize("quads", [2, 5])
+def test_round_two_with_several_quads_per_thread(ctx, oracle, quads):
+    """Round 2's num / den runs through the quad-blocked batch inversion with the multiplication fused (r06:
+    pm::fr_batch_inverse_mul).  At the sizes the C prover reaches, the library's own rule gives every thread ONE quad; option
+    binv_quads forces several (ragged last quads included: 2^12 / (4 * 5) does not divide), so that the scratch chain between
+    the quads and the fused product are compared with the C prover too -- z's commitment and every evaluation that depends on it."""
+    import plonk_prototype_amd as pa
+    import plonk_prototype_amd.prover as PR
+    from oracle import cpu_prover as CP
+    n = 1 << 12
+    circuit, wit, pub = _circuit(n, 4242, True)
+    srs = oracle.g1_bases_arith(ints_to_limbs([0xA5A5], 4)[0], ints_to_limbs([0x7FFFFFFF], 4)[0], n, 8)
+    ck = pa.CommitKey(srs, ctx)
+    pk = PR.preprocess(circuit, ctx, ck)
+    ref = PR.prove(pk, ck, wit, pub)
+    try:
+        ctx.set_option("binv_quads", quads)
+        proof = PR.prove(pk, ck, wit, pub)
+    finally:
+        ctx.set_option("binv_quads", 0)
+    assert proof.to_bytes() == ref.to_bytes()
+    cpk = CP.preprocess(oracle, {k: getattr(circuit, k) for k in CP.SELECTORS}, circuit.sigma_index, threads=8)
+    exp = CP.prove(oracle, cpk, srs, wit, pub, proof.challenges, threads=8)
+    assert np.array_equal(proof.commitments["z"], exp["commitments"]["z"])
+    assert np.array_equal(proof.evaluations["z_next"], exp["evaluations"]["z_next"])
+
+
 def test_round_kernels_empty_and_bad_arguments(ctx, oracle):
     """n == 0 is a no-op for every entry point; null pointers and bad sizes are reported, not executed."""
     import ctypes as C
