@@ -117,6 +117,9 @@ class Watchdog:
     deadline when a phase completes; when it passes, `on_timeout(phase)` runs (rank 0 prints the line with what there is)
     and EVERY rank leaves with a NON-ZERO code -- a hang must not read as success (r04 exited 0).
 
+    `abort_file`: a path the bare launcher (launch_ranks) creates as soon as one rank has exited with a non-zero code; the
+    watchdog polls it and treats its appearance like a passed deadline, so a rank that died at start-up costs its peers seconds,
+    not the ten minutes of the start-up deadline.
     `grace`: seconds added to every deadline of this rank.  Rank 0 runs with 0 and the other ranks with a few
     seconds, so that rank 0 -- the one that prints -- always fires first: under torch.distributed.run the first non-zero
     exit makes the agent SIGTERM the remaining ranks, and a rank other than 0 firing first could get rank 0 killed before
@@ -124,9 +127,10 @@ class Watchdog:
     the complete line is printed, ends with 0: the measurement is whole, only close / destroy hung)."""
     EXIT_CODE = 3
 
-    def __init__(self, seconds, on_timeout, phase="startup", exit_fn=os._exit, grace=0.0):
+    def __init__(self, seconds, on_timeout, phase="startup", exit_fn=os._exit, grace=0.0, abort_file=None):
         import threading
         self._grace = grace
+        self._abort_file = abort_file          # the bare launcher creates it when a peer rank has exited with an error
         self._deadline, self._phase, self._code = time.monotonic() + seconds + grace, phase, self.EXIT_CODE
         self._done, self._lock = threading.Event(), threading.Lock()
         self._on_timeout, self._exit = on_timeout, exit_fn
@@ -144,6 +148,13 @@ class Watchdog:
         while not self._done.wait(0.2):
             with self._lock:
                 late, phase, code = time.monotonic() > self._deadline, self._phase, self._code
+            if not late and self._abort_file and os.path.exists(self._abort_file):
+                # a peer is gone: whatever collective this rank sits in will never complete -- do now what the deadline would
+                # do later (the watchdog thread runs while the main thread is blocked in native code; a signal handler would not)
+                late, phase = True, f"{phase} -- cut short: a peer rank exited with an error (the launcher's abort file)"
+                if code == 0:
+                    code = self.EXIT_CODE
+                time.sleep(self._grace / 5.0)       # rank 0 first, as for a deadline
             if late:
                 try:
                     self._on_timeout(phase)
@@ -170,7 +181,11 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
     s_.close()
     base = dict(os.environ if env is None else env)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import tempfile
+    abort_dir = tempfile.mkdtemp(prefix="pm_bench_")
+    abort_file = os.path.join(abort_dir, "abort")
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                PM_BENCH_ABORT_FILE=abort_file)
     emitter = LineEmitter(json_fd)
     procs = []
     for r in range(n):
@@ -199,10 +214,20 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
     th.start()
     t_end = time.monotonic() + deadline_s
     timed_out = False
+    peer_failed = False
     while any(p.poll() is None for p in procs):
         if time.monotonic() > t_end:
             timed_out = True
             break
+        if not peer_failed and any(p.poll() not in (None, 0) for p in procs):
+            # a rank is gone: its peers' collectives cannot complete.  Tell their watchdogs (they print the line with what had
+            # finished and leave with a non-zero code) and give them a bounded time to do so
+            peer_failed = True
+            bad = [(i, p.returncode) for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+            log(f"[bench] launcher: rank(s) {bad} exited with an error; signalling the others through {abort_file}")
+            with open(abort_file, "w") as f_:
+                f_.write(repr(bad))
+            t_end = min(t_end, time.monotonic() + 90)
         time.sleep(0.1)
     if timed_out:
         alive = [p for p in procs if p.poll() is None]
@@ -220,6 +245,12 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
     th.join(5)
     codes = [p.returncode if p.returncode >= 0 else 128 - p.returncode for p in procs]
     log(f"[bench] launcher: rank exit codes {codes}")
+    try:
+        if os.path.exists(abort_file):
+            os.unlink(abort_file)
+        os.rmdir(abort_dir)
+    except OSError:
+        pass
     rc = max(codes)
     if timed_out:
         rc = max(rc, Watchdog.EXIT_CODE + 1)
@@ -311,7 +342,7 @@ def main():
                          "(pm_fr_ntt_fourstep_dev, SURVEY 8f N5) through the library's RCCL communicator")
     ap.add_argument("--launcher-timeout", type=int, default=0,
                     help="bare `--gpus N` (no torch.distributed.run around it): seconds the N child ranks may take in all; "
-                         "0 = --startup-timeout + --leg-timeout + 240")
+                         "0 = --startup-timeout + 2 x --leg-timeout + 300 (the ranks' own watchdogs end them before that)")
     ap.add_argument("--child-cmd", default=None,
                     help="bare `--gpus N` only: the command each rank runs instead of this script (tests drive the launcher "
                          "with a stub child)")
@@ -323,7 +354,7 @@ def main():
         import shlex
         cmd = shlex.split(args.child_cmd) if args.child_cmd else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(launch_ranks(args.gpus, cmd, json_fd,
-                              args.launcher_timeout or args.startup_timeout + args.leg_timeout + 240))
+                              args.launcher_timeout or args.startup_timeout + 2 * args.leg_timeout + 300))
 
     import torch
     import torch.distributed as dist
@@ -364,7 +395,7 @@ def main():
                                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                                   "note": note})
         dog = Watchdog(args.startup_timeout, on_timeout, "process group + communicator + headline",
-                       grace=0.0 if rank == 0 else 10.0)
+                       grace=0.0 if rank == 0 else 10.0, abort_file=os.environ.get("PM_BENCH_ABORT_FILE"))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

@@ -180,6 +180,17 @@ assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"
 assert int(os.environ["LOCAL_RANK"]) == rank
 if mode == "silent":
     time.sleep(120)                       # the rank that never prints
+if mode == "peerdies":
+    # rank 1 dies at start-up; rank 0 sits "in a collective" under the real watchdog, which the launcher's abort file cuts short
+    if rank == 1:
+        sys.exit(7)
+    sys.path.insert(0, sys.argv[3])
+    import bench
+    fd = os.dup(1)
+    em = bench.LineEmitter(fd)
+    dog = bench.Watchdog(600, lambda phase: em.emit({"metric": "m", "value": None, "note": "watchdog: " + phase}), "startup",
+                         abort_file=os.environ.get("PM_BENCH_ABORT_FILE"))
+    time.sleep(120)
 if rank == 0:
     print("RCCL banner on stdout", flush=True)
     print(json.dumps({"metric": "m", "value": 1.0, "world": world, "rank": rank}), flush=True)
@@ -199,7 +210,7 @@ def _run_launcher(tmp_path, mode, n=2, deadline=30):
     stub.write_text(_STUB)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launcher-timeout", str(deadline),
-                        "--child-cmd", f"{sys.executable} {stub} {mode} {tmp_path}"],
+                        "--child-cmd", f"{sys.executable} {stub} {mode} {tmp_path} {ROOT}"],
                        capture_output=True, text=True, timeout=120, env=env)
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     return p.returncode, lines, p.stderr
@@ -270,3 +281,17 @@ def test_other_ranks_fire_after_rank_zero_and_teardown_hang_exits_zero():
     assert 0.5 <= r0[0][1] < 1.2 and r1[0][1] >= 1.5              # the grace separates them
     td = _run_grace(0.0, True)
     assert td[0][0] == "teardown" and td[1] == 0
+
+
+def test_a_rank_that_dies_at_start_up_costs_its_peers_seconds_not_the_deadline(tmp_path):
+    """Rank 1 exits with code 7 before any collective; rank 0 is blocked under its 600 s start-up watchdog.  The launcher
+    creates the abort file, rank 0's watchdog prints the line (value null, the reason in the note) and leaves with code 3; the
+    launcher returns the largest code -- all within seconds."""
+    import time
+    t0 = time.monotonic()
+    rc, lines, err = _run_launcher(tmp_path, "peerdies", deadline=300)
+    assert time.monotonic() - t0 < 30, err
+    assert rc == 7 and len(lines) == 1, (rc, lines, err)
+    line = json.loads(lines[0])
+    assert line["value"] is None and "a peer rank exited" in line["note"]
+    assert "signalling the others" in err and "[3, 7]" in err
