@@ -169,6 +169,39 @@ def test_prover_round_kernels_random_shapes(ctx, oracle):
         assert ints(num) == en and ints(den) == ed, ("perm", case, n)
 
 
+def test_poly_helpers_random_shapes(ctx, oracle):
+    """Ruffini (scaled prefix sum: tiles of 2048, tile carries inside the replay kernel up to 512 tiles), batch inversion
+    (quad-blocked, several quads per thread forced through option binv_quads, random zero patterns) and prefix product (zero
+    factors, all three scan modes) on random lengths around the tile / chunk / quad boundaries, against the C oracle."""
+    import plonk_prototype_amd as pa
+    rng = np.random.default_rng(6060842 + SEED)
+    edge = oracle.fr_to_mont(ints_to_limbs([0, 1, 2, B.R_MOD - 1, B.R_MOD - 2, (1 << 255) % B.R_MOD], 4))
+    near = [1, 2, 3, 4, 5, 7, 8, 9, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6145]
+    try:
+        for case in range(40 * SCALE):
+            n = int(rng.choice(near)) if rng.random() < 0.4 else int(rng.integers(1, 70000))
+            a = oracle.fr_sample(7000 + case + 100000 * SEED, n)
+            salt = rng.random(n) < rng.choice([0.0, 0.01, 0.3])
+            a[salt] = edge[rng.integers(0, len(edge), size=int(salt.sum()))]
+            # Ruffini at a random, a tiny and a huge point
+            z = [oracle.fr_sample(9000 + case, 1)[0], edge[int(rng.integers(0, len(edge)))]][int(rng.integers(0, 2))]
+            q = pa.Polynomial.from_host(ctx, a).ruffini(z).to_host()
+            assert np.array_equal(q, oracle.fr_poly_ruffini(a, z)), ("ruffini", case, n)
+            # batch inversion: zeros stay, everything else inverts; the quads per thread forced
+            quads = int(rng.choice([0, 1, 2, 3, 5, 16]))
+            ctx.set_option("binv_quads", quads)
+            got = pa.Polynomial.from_host(ctx, a).batch_inverse().to_host()
+            assert np.array_equal(got, oracle.fr_batch_inverse(a)), ("batch_inverse", case, n, quads)
+            ctx.set_option("binv_quads", 0)
+            # prefix product
+            ctx.set_option("poly_lookback", int(rng.integers(0, 3)))
+            assert np.array_equal(pa.Polynomial.from_host(ctx, a).prefix_product().to_host(), oracle.fr_prefix_product(a)), ("prefix", case, n)
+            ctx.set_option("poly_lookback", 1)
+    finally:
+        ctx.set_option("binv_quads", 0)
+        ctx.set_option("poly_lookback", 1)
+
+
 def test_prove_many_seeds(ctx, oracle):
     """Several circuits (arithmetic-only and with every widget) and sizes: every proof must satisfy the
     verifier identity, the serialised proof must round-trip, and a second proof from the same key
