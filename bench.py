@@ -337,6 +337,9 @@ def main():
     ap.add_argument("--startup-timeout", type=int, default=600,
                     help="N > 1: seconds the process group, the communicator and the headline may take before the watchdog "
                          "ends every rank with a non-zero code (armed before the first collective)")
+    ap.add_argument("--comm-timeout-ms", type=int, default=180000,
+                    help="N > 1 with the library's RCCL communicator: option comm_timeout_ms of the context (0 = off); well above "
+                         "any legitimate exchange, below --leg-timeout")
     ap.add_argument("--fourstep-log-n", type=int, default=0,
                     help="N > 1 only, off by default: also time ONE 2^K transform split over the ranks "
                          "(pm_fr_ntt_fourstep_dev, SURVEY 8f N5) through the library's RCCL communicator")
@@ -426,6 +429,10 @@ def main():
     native_comm = False
     if world > 1 and backend == "nccl":
         native_comm = setup_native_comm(ctx, rank, world, dist, coll_dev, lambda m_: print(m_, file=sys.stderr, flush=True))
+        if native_comm and args.comm_timeout_ms > 0:
+            # a peer that dies inside an exchange: the library ends the blocked call with ncclCommAbort after this long and the
+            # leg records an error (every later leg on this communicator fails at once) instead of the watchdog ending the run
+            ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
         # self-diagnosing first multi-GPU run: every rank says what communicator it ended up with
         import ctypes as _C
         _r, _w = _C.c_int(-1), _C.c_int(-1)
