@@ -4,7 +4,7 @@
 # CPU only -- GPU sanitizer runs are not available on this pool.   usage: bash tools/host_asan.sh
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
-TESTS="tests/test_msm_geometry.py tests/test_ntt_plan.py tests/test_abi.py tests/test_transcript.py tests/test_domain_helpers.py"
+TESTS="tests/test_msm_geometry.py tests/test_ntt_plan.py tests/test_abi.py tests/test_transcript.py tests/test_domain_helpers.py tests/test_comm_deadline.py"
 for SAN in address undefined; do
   B=$R/build_ab/san_${SAN}
   mkdir -p $B
