@@ -212,11 +212,18 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
 
     th = threading.Thread(target=relay, daemon=True)
     th.start()
+    # the launcher itself may be told to stop (the caller's own timeout: SIGTERM; Ctrl-C): the ranks must not outlive it
+    import signal
+    stop = {"sig": None}
+
+    def on_signal(signum, _frame):
+        stop["sig"] = signum
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     t_end = time.monotonic() + deadline_s
     timed_out = False
     peer_failed = False
     while any(p.poll() is None for p in procs):
-        if time.monotonic() > t_end:
+        if time.monotonic() > t_end or stop["sig"] is not None:
             timed_out = True
             break
         if not peer_failed and any(p.poll() not in (None, 0) for p in procs):
@@ -231,8 +238,8 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
         time.sleep(0.1)
     if timed_out:
         alive = [p for p in procs if p.poll() is None]
-        log(f"[bench] launcher: deadline of {deadline_s:.0f} s passed with ranks {[procs.index(p) for p in alive]} still running; "
-            f"terminating them")
+        why = f"signal {stop['sig']} received" if stop["sig"] is not None else f"deadline of {deadline_s:.0f} s passed"
+        log(f"[bench] launcher: {why} with ranks {[procs.index(p) for p in alive]} still running; terminating them")
         for p in alive:
             p.terminate()
         t_kill = time.monotonic() + 10
@@ -243,6 +250,8 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
                 p.kill()
                 p.wait()
     th.join(5)
+    for sg, h_ in old_handlers.items():
+        signal.signal(sg, h_)
     codes = [p.returncode if p.returncode >= 0 else 128 - p.returncode for p in procs]
     log(f"[bench] launcher: rank exit codes {codes}")
     try:
@@ -253,12 +262,13 @@ def launch_ranks(n, child_cmd, json_fd, deadline_s, env=None, log=lambda s: prin
         pass
     rc = max(codes)
     if timed_out:
-        rc = max(rc, Watchdog.EXIT_CODE + 1)
+        rc = max(rc, Watchdog.EXIT_CODE + 1 if stop["sig"] is None else 128 + stop["sig"])
     if not emitter.printed:
         emitter.emit({"metric": "bls12_381_fr_ntt_butterflies_per_s", "value": None, "unit": "butterflies/s", "n_gpus": n,
                       "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                       "note": f"launcher: rank 0 printed no line (rank exit codes {codes}"
-                              + (f", deadline of {deadline_s:.0f} s passed" if timed_out else "") + ")"})
+                              + (f", signal {stop['sig']}" if stop["sig"] is not None else
+                                 f", deadline of {deadline_s:.0f} s passed" if timed_out else "") + ")"})
         rc = max(rc, 1)
     return rc
 

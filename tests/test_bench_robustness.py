@@ -295,3 +295,27 @@ def test_a_rank_that_dies_at_start_up_costs_its_peers_seconds_not_the_deadline(t
     line = json.loads(lines[0])
     assert line["value"] is None and "a peer rank exited" in line["note"]
     assert "signalling the others" in err and "[3, 7]" in err
+
+
+def test_a_terminated_launcher_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to the launcher (the caller's own timeout): the ranks are terminated, a null line says why, the exit code is 128 + 15."""
+    import signal
+    import time
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-timeout", "300",
+                          "--child-cmd", f"{sys.executable} {stub} silent {tmp_path} {ROOT}"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    t0 = time.monotonic()
+    while not all((tmp_path / f"pid{r}").exists() for r in range(2)) and time.monotonic() - t0 < 60:
+        time.sleep(0.1)
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert p.returncode == 128 + 15 and len(lines) == 1 and "signal 15" in json.loads(lines[0])["note"], (p.returncode, out, err)
+    for r in range(2):
+        pid = int((tmp_path / f"pid{r}").read_text())
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
