@@ -106,6 +106,47 @@ def test_prefix_product(ctx, oracle, n):
         ctx.set_option("poly_lookback", 1)
 
 
+@pytest.mark.parametrize("log_n", [24, 26])
+def test_full_size_properties(ctx, oracle, log_n):
+    """BASELINE.json's sizes (2^24 = configs[4]'s vectors; 2^26 = its 4n domain) through size-independent properties, all on
+    the device: Ruffini through q(x)(x - z) + p(z) = p(x) at a random x (8193 / 32769 tiles: the carry kernel in several
+    sweeps); batch inversion through a * a^-1 = 1 with zeros staying zero (quads per thread at the rule's cap); the prefix
+    product through out[0] = 1 and out[k + 1] = out[k] a[k], checked on the whole vector with two vector products."""
+    import plonk_prototype_amd as pa
+    n = 1 << log_n
+    host = oracle.fr_sample(4242 + log_n, n)
+    host[7] = 0
+    host[n - 2] = 0
+    a = pa.DeviceVector.from_host(ctx, host)
+    out = pa.DeviceVector(ctx, n)
+    tmp = pa.DeviceVector(ctx, n)
+    fi = pa.field.fr_from_limbs
+    one = oracle.fr_to_mont(ints_to_limbs([1], 4))[0]
+    # Ruffini
+    z, x = oracle.fr_sample(1, 1)[0], oracle.fr_sample(2, 1)[0]
+    ctx.fr_ruffini(a.ptr, n, z, out.ptr)
+    px, pz, qx = fi(ctx.fr_evaluate(a.ptr, n, x)), fi(ctx.fr_evaluate(a.ptr, n, z)), fi(ctx.fr_evaluate(out.ptr, n - 1, x))
+    assert (qx * (fi(x) - fi(z)) + pz - px) % B.R_MOD == 0
+    # batch inversion (in place on a copy)
+    ctx._check(ctx._lib.pm_dev_upload(ctx._h, out._p, host.ctypes.data, n * 32))
+    ctx.fr_batch_inverse(out.ptr, n)
+    ctx.fr_vec_op(2, a.ptr, out.ptr, n, tmp.ptr, n)
+    prod = tmp.to_host()
+    assert not prod[7].any() and not prod[n - 2].any()
+    prod[7] = one
+    prod[n - 2] = one
+    assert (prod == one).all()
+    del prod
+    # prefix product: out[k + 1] == out[k] * a[k] for every k, out[0] == 1 (zeros in `a` make everything after them zero)
+    ctx.fr_prefix_product(a.ptr, n, out.ptr)
+    ctx.fr_vec_op(2, out.ptr, a.ptr, n, tmp.ptr, n)                  # tmp[k] = out[k] a[k]
+    got, want = out.to_host(), tmp.to_host()
+    assert np.array_equal(got[0], one) and np.array_equal(got[1:], want[:-1])
+    assert got[7].any() and not got[8:].any()                        # a[7] = 0: the product is zero from index 8 on
+    for v in (a, out, tmp):
+        v.free()
+
+
 def test_errors(ctx, oracle):
     import plonk_prototype_amd as pa
     a, b = _poly(ctx, oracle.fr_sample(1, 10)), _poly(ctx, oracle.fr_sample(2, 7))
