@@ -13,7 +13,9 @@ collective on the data path).  The same JSON line carries the MSM leg (configs[2
 G1 MSM; with N > 1 the points are sharded over the ranks and the 144-byte partials are
 all-gathered over RCCL and folded), the full-prove leg (configs[3]: a 2^20-gate synthetic circuit
 through the native prover: `prover`, with `prover.all_gate_kinds` = the same size with every widget selector
-present, and `prover.two_contexts_ms_per_proof` = two proofs in flight), the roofline of the dominant kernel from
+present, `prover.two_contexts_ms_per_proof` = two proofs in flight, and `prover.large` = BASELINE configs[4]: one
+2^24-gate proof through pm_plonk_prove and through pm_plonk_prove_dist -- one rank at N = 1, the N ranks otherwise),
+`msm.pcie_inclusive` (pm_g1_msm with host scalars: the CommitKey::commit drop-in signature), the roofline of the dominant kernel from
 live hipEvent timings, and the CPU baseline (the oracle's C restatement, timed on this box's host cores).
 `ntt_extra` holds the 2^24 transform (+ the rank-split transform's kernels on one rank), the PCIe-inclusive
 host-pointer call and the prover's coset shape; `ntt_fourstep` (N > 1, opt-in) one transform over all ranks.
