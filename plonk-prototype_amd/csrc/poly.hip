@@ -819,8 +819,16 @@ extern "C" int pm_fr_vec_op_dev(pm_ctx* ctx, int op, const void* d_a, const void
 // One evaluation batch, enqueued on `st` without a host synchronisation: the tables, partial sums and results of batch
 // number `slot` live in their own region of the context's polynomial workspace (`slot_bytes` apart), the results are copied
 // to `out` by the stream.  The caller holds ctx->mu and the polynomial resource group and synchronises the stream.
+// Coefficients per thread.  A workgroup ends in a 256-way sum through LDS (eight levels, two barriers each: ~480 instructions per
+// thread) -- as much as TWO Horner steps, so the segment must be long enough to amortise it, and a batch of k polynomials
+// brings k times the workgroups: L grows with k (r06: the prover's 15-polynomial opening at 2^20 ran L = 4, where the sum was
+// half of the kernel).  At least ~1024 workgroups for one polynomial, ~4096 in all for a batch.
+static u32 eval_len_per_thread(uint32_t k, size_t n) {
+  const size_t one = n / ((size_t)256 * 1024), many = n * (size_t)k / ((size_t)256 * 4096);
+  return (u32)std::max<size_t>(1, std::min<size_t>(64, std::max(one, many)));
+}
 static size_t eval_slot_bytes(uint32_t k, size_t n) {
-  const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
+  const u32 L = eval_len_per_thread(k, n);
   const size_t seg = (size_t)256 * L;
   const size_t nblocks = (n + seg - 1) / seg;
   return ((256 + (1 + (size_t)k) * nblocks) * 48 + 32 * (size_t)k + 64 + 255) / 256 * 256;
@@ -833,7 +841,7 @@ static int eval_enqueue(pm_ctx* ctx, hipStream_t st, uint32_t k, const void* con
     if (!d_polys[j]) return set_err(ctx, PM_ERR_BAD_ARG, "null device pointer");
     polys.p[j] = (const u32x4*)d_polys[j];
   }
-  const u32 L = (u32)std::max<size_t>(1, std::min<size_t>(64, n / ((size_t)256 * 1024)));
+  const u32 L = eval_len_per_thread(k, n);
   const size_t seg = (size_t)256 * L;
   const u32 nblocks = (u32)((n + seg - 1) / seg);
   HFr x;
